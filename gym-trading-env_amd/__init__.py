@@ -1,0 +1,29 @@
+"""MI355X-native batched drop-in for Gym-Trading-Env's step()/reset() hot path.
+
+Public surface (same names as src/gym_trading_env/environments.py):
+``TradingEnv``, ``MultiDatasetTradingEnv``, ``basic_reward_function``,
+``dynamic_feature_last_position_taken``, ``dynamic_feature_real_position``;
+plus ``BatchedTradingEnv``, the N-environment form the HIP kernels serve.
+Heavy imports (torch, the HIP library) happen on first use, not here.
+"""
+from . import _abi, config, staging  # noqa: F401
+from ._abi import GteError  # noqa: F401
+
+__all__ = ["TradingEnv", "MultiDatasetTradingEnv", "BatchedTradingEnv", "GteError",
+           "basic_reward_function", "dynamic_feature_last_position_taken",
+           "dynamic_feature_real_position"]
+
+_LAZY = {
+    "BatchedTradingEnv": "batched", "TradingEnv": "envs",
+    "MultiDatasetTradingEnv": "envs", "basic_reward_function": "envs",
+    "dynamic_feature_last_position_taken": "envs",
+    "dynamic_feature_real_position": "envs", "History": "history",
+}
+
+
+def __getattr__(name):
+    if name in _LAZY:
+        import importlib
+        mod = importlib.import_module(f"{__name__}.{_LAZY[name]}")
+        return getattr(mod, name)
+    raise AttributeError(name)

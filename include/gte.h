@@ -1,0 +1,217 @@
+/*
+ * gte.h — C ABI of libgte: the MI355X (gfx950) batched trading-environment
+ * hot path.
+ *
+ * The reference (ten2net/Gym-Trading-Env) is pure Python and has no FFI; the
+ * boundary it exposes is the Python class API of
+ * src/gym_trading_env/environments.py.  This header is the C ABI that sits
+ * directly under that class API: each entry point names the reference method
+ * (file:line) whose per-environment work it performs for a whole batch of
+ * environments resident in HBM.  The Python host layer
+ * (the Python files under gym-trading-env_amd/) binds these with ctypes;
+ * INTEGRATION.md shows the
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in any signature
+ *     (a hipStream_t travels as void*);
+ *   - every function returns 0 on success or a negative gte_status; the
+ *     message for the last failure on the calling thread is gte_last_error();
+ *   - the library owns all state, dataset and (unless gte_bind_outputs is
+ *     used) output buffers; pointers handed out stay valid until
+ *     gte_destroy; the host never frees them;
+ *   - all work is stream-ordered on the env's stream (gte_set_stream) and
+ *     asynchronous: gte_step returns after the launch;
+ *   - there is NO CPU fallback: every entry point that needs the device fails
+ *     with GTE_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef GTE_H_
+#define GTE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GTE_ABI_VERSION 1
+#define GTE_MAX_POSITIONS 32
+#define GTE_MAX_DYN 4
+
+typedef enum gte_status {
+  GTE_OK = 0,
+  GTE_ERR_INVALID = -1,    /* bad argument / config (message says which)     */
+  GTE_ERR_NO_DEVICE = -2,  /* no usable HIP device: there is no CPU fallback */
+  GTE_ERR_HIP = -3,        /* a HIP runtime call failed                      */
+  GTE_ERR_STATE = -4,      /* call order (e.g. step before upload/reset)     */
+  GTE_ERR_OOM = -5
+} gte_status;
+
+/* dynamic features computable on device
+ * (environments.py:20-24 dynamic_feature_last_position_taken / _real_position) */
+typedef enum gte_dyn_kind {
+  GTE_DYN_LAST_POSITION = 0,
+  GTE_DYN_REAL_POSITION = 1
+} gte_dyn_kind;
+
+/* rewards computable on device (environments.py:17-18 basic_reward_function;
+ * the clipped / scaled forms are the fork's luckymodel/envs/env.py:16-18) */
+typedef enum gte_reward_kind {
+  GTE_REWARD_LOG_RETURN = 0,         /* ln(pv_t / pv_{t-1})                    */
+  GTE_REWARD_SCALED_LOG_RETURN = 1,  /* reward_param0 * ln(pv_t / pv_{t-1})    */
+  GTE_REWARD_CLIPPED_LOG_RETURN = 2  /* clip(param0*ln(..), param1, param2)    */
+} gte_reward_kind;
+
+/* what a finished environment does on later steps.  The reference env never
+ * resets itself; Gymnasium's vector wrappers do
+ * (docs/source/vectorize_env.rst:17-33). */
+typedef enum gte_autoreset {
+  GTE_AUTORESET_DISABLED = 0,  /* caller resets (gte_reset with a mask)        */
+  GTE_AUTORESET_NEXT_STEP = 1, /* the step after a terminal one resets: it
+                                  ignores the action and returns the reset obs,
+                                  reward 0, flags false (Gymnasium >= 1.0)     */
+  GTE_AUTORESET_SAME_STEP = 2  /* terminal step returns the reset obs; flags
+                                  and reward are the terminal step's           */
+} gte_autoreset;
+
+/* Constructor arguments of TradingEnv (environments.py:79-93) for a batch. */
+typedef struct gte_config {
+  int32_t abi_version;      /* = GTE_ABI_VERSION                               */
+  int32_t struct_bytes;     /* = sizeof(gte_config)                            */
+  int32_t device;           /* HIP device ordinal                              */
+  int32_t n_envs;           /* N environments in this shard                    */
+  int32_t n_datasets;       /* D resident datasets (1 for TradingEnv)          */
+  int32_t n_static;         /* F_s: static feature columns (:130-133)          */
+  int32_t n_dyn;            /* dynamic features (:135-138), <= GTE_MAX_DYN     */
+  int32_t dyn_kind[GTE_MAX_DYN];
+  int32_t window;           /* W = `windows`; 0 means windows=None (:156-160)  */
+  int32_t n_positions;      /* P = len(positions) (:98)                        */
+  double  positions[GTE_MAX_POSITIONS];
+  double  trading_fees;            /* :102 */
+  double  borrow_interest_rate;    /* :103 */
+  double  portfolio_initial_value; /* :104 */
+  int32_t initial_position_index;  /* index into positions, or -1 = 'random' (:167) */
+  int32_t max_episode_duration;    /* 0 = 'max' (:173,:250)                    */
+  int32_t reward_kind;
+  int32_t autoreset;
+  double  reward_param0;
+  double  reward_param1;
+  double  reward_param2;
+  /* MultiDatasetTradingEnv (:365-400) */
+  int32_t episodes_between_dataset_switch; /* >= 1                             */
+  int32_t dyn_persist;      /* 1: keep a full T-deep dynamic-feature column per
+                               env across episodes, exactly like the in-place
+                               write into _obs_array (:153-154); 0: W-deep ring,
+                               rows before the episode start read as zero      */
+  uint64_t seed;            /* device Philox key for reset draws               */
+  int64_t  env_id_base;     /* global id of env 0 of this shard (RNG streams
+                               are keyed by global env id, so a sharded run
+                               equals the unsharded one)                       */
+  int32_t envs_per_wave;    /* 0 = choose automatically                        */
+  int32_t nontemporal_obs;  /* 1: stream observation stores past L2 (default 0)*/
+} gte_config;
+
+/* Device pointers of the per-step return values of TradingEnv.step
+ * (environments.py:272) for the whole batch. */
+typedef struct gte_outputs {
+  float*   obs;        /* f32 [N, W, F_obs] (or [N, F_obs] when window == 0)   */
+  float*   reward;     /* f32 [N]                                              */
+  double*  reward64;   /* f64 [N]  (the value the f32 one was rounded from)    */
+  uint8_t* terminated; /* u8  [N]  `done` (:246)                               */
+  uint8_t* truncated;  /* u8  [N]  (:248-251)                                  */
+  int32_t* term_count; /* i32 [1]  number of envs that ended this step         */
+  int32_t* term_ids;   /* i32 [N]  their ids, compacted (order unspecified)    */
+  int64_t  obs_elems_per_env; /* W*F_obs                                       */
+} gte_outputs;
+
+/* Device pointers of the per-env state (struct of arrays), i.e. the fields of
+ * TradingEnv/Portfolio that History logs each step (:253-264). */
+typedef struct gte_state_view {
+  int32_t* idx;            /* _idx (:235)                                      */
+  int32_t* step;           /* _step (:236)                                     */
+  int32_t* position_index; /* index of _position in positions (:210)           */
+  int32_t* dataset_index;  /* resident dataset the env trades                  */
+  int32_t* start_idx;      /* _idx at the last reset (for Market Return :281)  */
+  int32_t* episode;        /* number of resets so far                          */
+  int32_t* needs_reset;    /* 1 after a terminal step until the env is reset   */
+  double*  asset;          /* Portfolio.asset (portfolio.py:3)                 */
+  double*  fiat;           /* Portfolio.fiat                                   */
+  double*  interest_asset; /* Portfolio.interest_asset                         */
+  double*  interest_fiat;  /* Portfolio.interest_fiat                          */
+  double*  portfolio_valuation; /* valorisation at the current row (:241)      */
+  double*  real_position;  /* Portfolio.real_position at the current row (:259)*/
+} gte_state_view;
+
+typedef struct gte_env gte_env;
+
+/* TradingEnv.__init__ (environments.py:79-125): validates the arguments and
+ * allocates HBM for N envs and D datasets.  No data yet. */
+int gte_create(const gte_config* cfg, gte_env** out);
+
+/* TradingEnv._set_df (environments.py:128-143): uploads one staged dataset.
+ * feat  : host f32 [T, F_obs] row-major, F_obs = n_static + n_dyn, the n_dyn
+ *         trailing columns zero — exactly `_obs_array` (:141);
+ * close : host f64 [T] — `_price_array` (:143);
+ * high/low : host f64 [T] or NULL (only the limit-order path reads them, :221). */
+int gte_upload_dataset(gte_env* env, int32_t ds, const float* feat,
+                       const double* close, const double* high,
+                       const double* low, int64_t T);
+
+/* TradingEnv.reset (environments.py:163-199) for the envs with mask[i] != 0
+ * (mask == NULL: all).  All pointers are HOST arrays of length N or NULL.
+ * inj_idx / inj_pos_index / inj_dataset >= 0 replace the random draws of
+ * :174, :167 and :385 (parity mode); NULL or negative entries use the device
+ * Philox stream. */
+int gte_reset(gte_env* env, const uint8_t* mask, const int32_t* inj_idx,
+              const int32_t* inj_pos_index, const int32_t* inj_dataset);
+
+/* Queue values for the draws of later auto-resets: host i32 [N, n_episodes]
+ * arrays (or NULL) indexed by [env][k], k = 0 for the first auto-reset after
+ * this call.  Consumed in order; when exhausted the Philox stream takes over. */
+int gte_set_autoreset_injection(gte_env* env, int32_t n_episodes,
+                                const int32_t* inj_idx,
+                                const int32_t* inj_pos_index,
+                                const int32_t* inj_dataset);
+
+/* TradingEnv.step (environments.py:233-272) for all N envs in one launch:
+ * _take_action/_trade (:204-215) -> Portfolio.trade_to_position
+ * (portfolio.py:18-43) -> idx/step advance (:235-236) -> update_interest
+ * (portfolio.py:44-46) -> valorisation (portfolio.py:7-13) -> done/truncated
+ * (:244-251) -> reward (:17-18,:265-267) -> _get_obs (:152-160).
+ * actions: i32 [N] position indices, -1 = None (hold, :234); a host pointer,
+ * or a device pointer when actions_on_device != 0. */
+int gte_step(gte_env* env, const int32_t* actions, int32_t actions_on_device);
+
+/* Where the results of the last gte_step / gte_reset live (device pointers). */
+int gte_get_outputs(gte_env* env, gte_outputs* out);
+int gte_get_state(gte_env* env, gte_state_view* out);
+
+/* Use caller-owned device buffers for the outputs (e.g. torch tensors that are
+ * then all-gathered over RCCL).  NULL members keep the library's buffer. */
+int gte_bind_outputs(gte_env* env, const gte_outputs* bufs);
+
+/* Run on this hipStream_t (NULL = the library's own stream). */
+int gte_set_stream(gte_env* env, void* hip_stream);
+int gte_synchronize(gte_env* env);
+
+/* HIP-event timing on the env's stream, for bench.py's roofline figure. */
+int gte_timer_start(gte_env* env);
+int gte_timer_stop(gte_env* env, float* elapsed_ms); /* synchronises */
+
+/* Copies that the N=1 drop-in needs (synchronous, device -> host). */
+int gte_read_obs(gte_env* env, int32_t first_env, int32_t n, float* host_dst);
+
+/* kernel geometry actually used (for DESIGN.md / bench output) */
+int gte_get_launch_info(gte_env* env, int32_t* envs_per_wave,
+                        int32_t* threads_per_block, int32_t* n_blocks,
+                        int32_t* vector_bytes);
+
+void gte_destroy(gte_env* env);
+const char* gte_last_error(void);
+int gte_abi_version(void);
+int gte_device_count(void); /* usable HIP devices (0 on a CPU-only host)    */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GTE_H_ */
