@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the batched step() hot path on MI355X.
+
+One "step" = one gte_step launch over every environment of the rank's shard
+(TradingEnv.step for N envs, reference environments.py:233-272), observations
+left on the device.  Workload (BASELINE.json configs[2]): 65 536 envs
+per GPU, synthetic random-walk OHLCV T = 100 000, 30 static + 2 dynamic features,
+window 20 (obs 20x32 f32), positions [-1, 0, 1], fees 1e-4, borrow interest 3e-6
+(margin path live), random starts with max_episode_duration = 500, next-step
+auto-reset, uniform random actions pre-generated on the device.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the step kernel against the
+8 TB/s HBM peak with the ALGORITHMIC bytes of SURVEY §8d (5 250 B per env-step at
+this shape); `cpu_baseline` is the oracle's C restatement (oracle/, a "port")
+timed on this box's host cores on a bounded sample of the same workload.
+
+Multi-GPU (torchrun, one rank per GPU): envs shard with no data-path collective
+except the per-step RCCL all-gather of (reward, terminated, truncated) — 6 bytes
+per env — which is what the north star names; --gather-obs adds the observation
+all-gather (xGMI-bound, SURVEY §7 hard part 7).  Weak scaling: 65 536 envs/GPU.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (n_static, windows, T, max_episode_duration)
+    "c3": dict(n_static=30, windows=20, T=100_000, max_episode_duration=500, envs=65_536),
+    "c2": dict(n_static=14, windows=None, T=100_000, max_episode_duration=500, envs=4_096),
+}
+
+
+def synthetic_dataset(dataset_id: int, T: int, n_static: int):
+    """close = 100*exp(cumsum(N(0, 1e-3))), features N(0,1) f32."""
+    rng = np.random.default_rng(1234 + dataset_id)
+    close = 100.0 * np.exp(np.cumsum(rng.normal(0.0, 1e-3, T)))
+    feat = rng.normal(0.0, 1.0, (T, n_static)).astype(np.float32)
+    return feat, close
+
+
+def algorithmic_bytes(W: int, F_obs: int, F_s: int, n_dyn: int) -> int:
+    """SURVEY §8d B_alg per env-step."""
+    return 4 * W * F_obs + 4 * W * F_s + 8 + 104 + 4 * W * n_dyn + 4 * n_dyn + 4 + 6
+
+
+def env_kwargs(wl):
+    return dict(positions=[-1, 0, 1], windows=wl["windows"], trading_fees=1e-4,
+                borrow_interest_rate=3e-6, portfolio_initial_value=1000,
+                initial_position="random", max_episode_duration=wl["max_episode_duration"],
+                autoreset="next_step")
+
+
+def cpu_baseline(wl, seconds_target: float = 12.0):
+    """Time the ORACLE (oracle/gte_oracle.c, OpenMP over envs) on the host cores on a
+    bounded sample of the same workload.  Reported baseline only; never the product."""
+    from gym_trading_env_amd.config import make_config
+    from oracle import oracle
+    oracle.build()
+    cores = len(os.sched_getaffinity(0))
+    n_envs, n_dyn = 65_536, 2
+    feat, close = synthetic_dataset(0, wl["T"], wl["n_static"])
+    full = np.zeros((wl["T"], wl["n_static"] + n_dyn), np.float32)
+    full[:, :wl["n_static"]] = feat
+    cfg = make_config(n_envs=n_envs, n_static=wl["n_static"], seed=7, **env_kwargs(wl))
+    env = oracle.OracleEnv(cfg, [(full, close)])
+    env.reset()
+    rng = np.random.default_rng(99)
+    acts = rng.integers(0, 3, (32, n_envs)).astype(np.int32)
+    for i in range(3):
+        env.step(acts[i], threads=cores)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        env.step(acts[steps % 32], threads=cores)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > seconds_target or steps >= 4000:
+            break
+    env.close()
+    return {"value": n_envs * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n_envs} envs x {steps} steps of the same workload, oracle C restatement "
+                      f"with OpenMP on {cores} threads, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's)")
+    ap.add_argument("--epw", type=int, default=0, help="envs per wavefront (0 = auto)")
+    ap.add_argument("--nt", type=int, default=0, help="1: non-temporal observation stores")
+    ap.add_argument("--gather-obs", action="store_true", help="also all-gather observations (N>1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the env has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+
+    wl = WORKLOADS[args.workload]
+    N = args.envs or wl["envs"]
+    n_dyn = 2
+    W = wl["windows"] or 1
+    F_obs = wl["n_static"] + n_dyn
+    feat, close = synthetic_dataset(0, wl["T"], wl["n_static"])
+    env = BatchedTradingEnv((feat, close), num_envs=N, seed=20240607, env_id_base=rank * N,
+                            device=local_rank, output="torch", envs_per_wave=args.epw,
+                            nontemporal_obs=bool(args.nt), **env_kwargs(wl))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99 + rank)
+    n_rows = 64
+    actions = torch.randint(0, 3, (n_rows, N), dtype=torch.int32, device=dev, generator=gen)
+    env.reset()
+
+    # per-step return of a sharded run: one RCCL all-gather of the packed
+    # (reward f32 | terminated u8 | truncated u8) records, 6 bytes per env
+    packed = gathered = obs_all = None
+    if world > 1:
+        packed = torch.empty(6 * N, dtype=torch.uint8, device=dev)
+        gathered = torch.empty(world * 6 * N, dtype=torch.uint8, device=dev)
+        if args.gather_obs:
+            obs_all = torch.empty((world * N, W, F_obs), dtype=torch.float32, device=dev)
+
+    def one_step(i):
+        obs, reward, term, trunc, _ = env.step(actions[i % n_rows])
+        if world > 1:
+            packed[:4 * N].copy_(reward.view(torch.uint8))
+            packed[4 * N:5 * N].copy_(term.view(torch.uint8))
+            packed[5 * N:].copy_(trunc.view(torch.uint8))
+            dist.all_gather_into_tensor(gathered, packed)
+            if obs_all is not None:
+                dist.all_gather_into_tensor(obs_all, obs.view(N, W, F_obs))
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    env.timer_start()  # HIP events on the stream the kernel is launched on
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    ev_ms = env.timer_stop()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el, ev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el, ev_ms = float(t[0]), float(t[1])
+
+    # episodes really end inside the timed region (auto-reset is part of the step)
+    episodes = int(env.state("episode").sum())
+    info = env.launch_info()
+    b_alg = algorithmic_bytes(W, F_obs, wl["n_static"], n_dyn)
+    kernel_us = ev_ms * 1e3 / args.steps
+    achieved = b_alg * N / (kernel_us * 1e-6) / 1e9
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get(f"{args.workload}_bytes_per_launch")
+        except Exception:
+            traffic = None
+    if rank == 0:
+        out = {
+            "metric": "env-steps/sec", "value": world * N * args.steps / el, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": el * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 state / f32 obs", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {N} envs/GPU x obs ({W},{F_obs}) f32, "
+                                   f"T={wl['T']}, positions [-1,0,1], fees 1e-4, borrow 3e-6, "
+                                   f"max_episode_duration {wl['max_episode_duration']}, next-step autoreset",
+                       "envs_per_gpu": N, "global_envs": world * N,
+                       "parallelism": f"env-shard x{world}" + (
+                           "" if world == 1 else " + RCCL all-gather(reward,flags"
+                           + (",obs)" if args.gather_obs else ")")),
+                       "launch": info, "nontemporal_obs": bool(args.nt),
+                       "episodes_finished": episodes},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_env_step": b_alg,
+                         "kernel_us_per_launch": kernel_us},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -138,6 +138,7 @@ SYMBOLS = {
     "gte_timer_start": (C.c_int, [C.c_void_p]),
     "gte_timer_stop": (C.c_int, [C.c_void_p, _P(C.c_float)]),
     "gte_read_obs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "gte_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "gte_get_launch_info": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_int32),
                                       _P(C.c_int32), _P(C.c_int32)]),
     "gte_destroy": (None, [C.c_void_p]),

@@ -1,0 +1,335 @@
+"""BatchedTradingEnv — N reference-semantics TradingEnvs stepped by one HIP launch.
+
+Host-side mirror of the reference's `TradingEnv` surface
+(src/gym_trading_env/environments.py:79-125 constructor, :163 reset, :233 step)
+for a batch: same argument names and meaning, same asserts, `step(actions)`
+returning `(obs, reward, terminated, truncated, info)`.  All arithmetic happens
+in libgte's kernels (csrc/); this file only stages data, marshals pointers and
+wraps device buffers.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi, spaces, staging
+from .config import make_config
+
+_NP = {"int32": np.int32, "float64": np.float64}
+
+
+def _as_staged(ds, n_dyn, name="Stock"):
+    if isinstance(ds, staging.StagedDataset):
+        return ds
+    if isinstance(ds, tuple) and len(ds) == 2:
+        return staging.stage_arrays(ds[0], ds[1], n_dyn=n_dyn, name=name)
+    return staging.stage_dataframe(ds, n_dyn=n_dyn, name=name)  # a pandas DataFrame
+
+
+class LazyInfo(dict):
+    """`info` of a batched step: struct-of-arrays view of what the reference logs in
+    `History` each step (environments.py:253-264), fetched from HBM only on access.
+
+    Keys follow History's flattened column names (docs/source/history.rst:18-46):
+    idx, step, position_index, position, real_position, portfolio_valuation,
+    portfolio_distribution_{asset,fiat,borrowed_asset,borrowed_fiat,interest_asset,
+    interest_fiat}, reward, data_close, dataset_index."""
+
+    _KEYS = ("idx", "step", "position_index", "position", "real_position",
+             "portfolio_valuation", "portfolio_distribution_asset",
+             "portfolio_distribution_fiat", "portfolio_distribution_borrowed_asset",
+             "portfolio_distribution_borrowed_fiat", "portfolio_distribution_interest_asset",
+             "portfolio_distribution_interest_fiat", "reward", "data_close", "dataset_index")
+
+    def __init__(self, env):
+        super().__init__()
+        self._env = env
+
+    def keys(self):
+        return list(self._KEYS)
+
+    def __contains__(self, k):
+        return k in self._KEYS
+
+    def __iter__(self):
+        return iter(self._KEYS)
+
+    def __len__(self):
+        return len(self._KEYS)
+
+    def __missing__(self, key):
+        e = self._env
+        if key in ("idx", "step", "position_index", "real_position", "portfolio_valuation",
+                   "dataset_index"):
+            v = e.state(key)
+        elif key == "position":
+            v = np.asarray(e.positions, dtype=np.float64)[e.state("position_index")]
+        elif key == "reward":
+            v = e.read_output("reward64")
+        elif key == "data_close":
+            ds, idx = e.state("dataset_index"), e.state("idx")
+            v = np.array([e.datasets[d].close[i] for d, i in zip(ds, idx)])
+        elif key.startswith("portfolio_distribution_"):
+            # Portfolio.get_portfolio_distribution, portfolio.py:49-57
+            f = key[len("portfolio_distribution_"):]
+            if f in ("interest_asset", "interest_fiat"):
+                v = e.state(f)
+            else:
+                src = e.state("asset" if f.endswith("asset") else "fiat")
+                v = np.maximum(0.0, -src if f.startswith("borrowed") else src)
+        else:
+            raise KeyError(key)
+        self[key] = v
+        return v
+
+
+class BatchedTradingEnv:
+    """N independent trading environments resident in HBM.
+
+    Parameters mirror `TradingEnv.__init__` (environments.py:79-93); the extra ones:
+
+    :param df: one dataset or a list of datasets: pandas DataFrames (feature columns
+        contain "feature", a "close" column), ``StagedDataset`` objects, or
+        ``(features[T, F_s], close[T])`` tuples.  Several datasets give the
+        `MultiDatasetTradingEnv` behaviour (:365-400) with all of them resident.
+    :param num_envs: N.
+    :param autoreset: None/"disabled", "next_step" (Gymnasium >= 1.0) or "same_step".
+    :param output: "torch" — observations/rewards/flags stay on the device as torch
+        tensors (zero-copy views of the buffers the kernel writes); "numpy" — copied to
+        host each step (compatibility mode).
+    :param dyn_persist: keep the per-env dynamic-feature column across episodes like
+        the reference's in-place write into `_obs_array` (:153-154); costs
+        N*T*n_dyn*4 bytes of HBM.
+    """
+
+    metadata = {"render_modes": ["logs"]}
+
+    def __init__(self, df, num_envs: int, positions=(0, 1),
+                 dynamic_feature_functions=("last_position_taken", "real_position"),
+                 reward_function="basic_reward_function", windows=None, trading_fees=0,
+                 borrow_interest_rate=0, portfolio_initial_value=1000,
+                 initial_position="random", max_episode_duration="max", verbose=1,
+                 name="Stock", render_mode="logs", *, autoreset="next_step",
+                 episodes_between_dataset_switch=1, dyn_persist=False, seed=0,
+                 env_id_base=0, device=0, output="torch", envs_per_wave=0,
+                 nontemporal_obs=False, library_path=None):
+        assert render_mode is None or render_mode in self.metadata["render_modes"]
+        if output not in ("torch", "numpy"):
+            raise ValueError("output must be 'torch' or 'numpy'")
+        self.positions = list(positions)
+        self.windows = windows
+        self.verbose, self.name, self.render_mode = verbose, name, render_mode
+        self.num_envs = int(num_envs)
+        self.output = output
+        self._lib = _abi.load_library(library_path)  # raises if the HIP build is missing
+        self._h = C.c_void_p()
+
+        from .config import resolve_dynamic_features
+        n_dyn = len(resolve_dynamic_features(dynamic_feature_functions))
+        raw = list(df) if isinstance(df, (list, tuple)) and not (
+            isinstance(df, tuple) and len(df) == 2 and hasattr(df[0], "shape")) else [df]
+        self.datasets = [_as_staged(d, n_dyn, name) for d in raw]
+        first = self.datasets[0]
+        for d in self.datasets:
+            if d.n_static != first.n_static or d.n_dyn != n_dyn:
+                raise ValueError("all datasets must have the same feature columns")
+            staging.check_episode_geometry(d.T, windows, max_episode_duration)
+
+        self.cfg = make_config(
+            n_envs=self.num_envs, n_static=first.n_static, n_datasets=len(self.datasets),
+            positions=self.positions, dynamic_feature_functions=dynamic_feature_functions,
+            reward_function=reward_function, windows=windows, trading_fees=trading_fees,
+            borrow_interest_rate=borrow_interest_rate,
+            portfolio_initial_value=portfolio_initial_value,
+            initial_position=initial_position, max_episode_duration=max_episode_duration,
+            autoreset=autoreset, episodes_between_dataset_switch=episodes_between_dataset_switch,
+            dyn_persist=dyn_persist, seed=seed, env_id_base=env_id_base, device=device,
+            envs_per_wave=envs_per_wave, nontemporal_obs=nontemporal_obs)
+        _abi.check(self._lib, self._lib.gte_create(C.byref(self.cfg), C.byref(self._h)))
+
+        self.n_obs = first.n_static + n_dyn
+        self.obs_shape = (self.n_obs,) if windows is None else (int(windows), self.n_obs)
+        # environments.py:112-123
+        self.single_action_space = spaces.Discrete(len(self.positions))
+        self.single_observation_space = spaces.Box(-np.inf, np.inf, shape=self.obs_shape)
+        self.action_space = spaces.MultiDiscrete([len(self.positions)] * self.num_envs)
+        self.observation_space = spaces.Box(-np.inf, np.inf,
+                                            shape=(self.num_envs,) + self.obs_shape)
+        for d, s in enumerate(self.datasets):
+            self.upload_dataset(d, s)
+
+        self._state = _abi.GteStateView()
+        _abi.check(self._lib, self._lib.gte_get_state(self._h, C.byref(self._state)))
+        self._torch = None
+        self._t = {}
+        if output == "torch":
+            self._bind_torch_outputs()
+        self._out = _abi.GteOutputs()
+        _abi.check(self._lib, self._lib.gte_get_outputs(self._h, C.byref(self._out)))
+        self._was_reset = False
+
+    # -- setup ---------------------------------------------------------------------
+    def upload_dataset(self, d: int, s: staging.StagedDataset):
+        """`_set_df` (environments.py:128-143): stage one dataset into HBM."""
+        feat = np.ascontiguousarray(s.feat, dtype=np.float32)
+        close = np.ascontiguousarray(s.close, dtype=np.float64)
+        ptr = lambda a: None if a is None else np.ascontiguousarray(a, np.float64).ctypes.data
+        _abi.check(self._lib, self._lib.gte_upload_dataset(
+            self._h, d, feat.ctypes.data, close.ctypes.data, ptr(s.high), ptr(s.low), s.T))
+        self.datasets[d] = s
+
+    def _bind_torch_outputs(self):
+        import torch
+        if not torch.cuda.is_available():
+            raise _abi.GteError(_abi.GTE_ERR_NO_DEVICE, "torch sees no GPU; there is no CPU fallback")
+        self._torch = torch
+        dev = torch.device("cuda", self.cfg.device)
+        N = self.num_envs
+        with torch.cuda.device(dev):
+            self._t = {
+                "obs": torch.zeros((N,) + self.obs_shape, dtype=torch.float32, device=dev),
+                "reward": torch.zeros(N, dtype=torch.float32, device=dev),
+                "reward64": torch.zeros(N, dtype=torch.float64, device=dev),
+                "terminated": torch.zeros(N, dtype=torch.bool, device=dev),
+                "truncated": torch.zeros(N, dtype=torch.bool, device=dev),
+                "term_count": torch.zeros(1, dtype=torch.int32, device=dev),
+                "term_ids": torch.zeros(N, dtype=torch.int32, device=dev),
+            }
+            torch.cuda.synchronize(dev)
+            b = _abi.GteOutputs()
+            for k, t in self._t.items():
+                setattr(b, k, t.data_ptr())
+            _abi.check(self._lib, self._lib.gte_bind_outputs(self._h, C.byref(b)))
+            # run on torch's current stream so torch ops and env launches are ordered
+            _abi.check(self._lib, self._lib.gte_set_stream(
+                self._h, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+
+    # -- data movement helpers -------------------------------------------------------
+    def _to_host(self, dev_ptr: int, dtype, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        _abi.check(self._lib, self._lib.gte_copy_to_host(self._h, C.c_void_p(dev_ptr),
+                                                         out.ctypes.data, out.nbytes))
+        return out
+
+    def state(self, name: str) -> np.ndarray:
+        """Host copy of one per-env state array (struct gte_state_view member)."""
+        dt = _NP[_abi.STATE_DTYPES[name]]
+        return self._to_host(getattr(self._state, name), dt, self.num_envs)
+
+    def read_output(self, name: str) -> np.ndarray:
+        """Host copy of one output array of the last step/reset."""
+        N = self.num_envs
+        spec = {"obs": (np.float32, N * int(np.prod(self.obs_shape))),
+                "reward": (np.float32, N), "reward64": (np.float64, N),
+                "terminated": (np.uint8, N), "truncated": (np.uint8, N),
+                "term_count": (np.int32, 1), "term_ids": (np.int32, N)}[name]
+        a = self._to_host(getattr(self._out, name), *spec)
+        return a.reshape((N,) + self.obs_shape) if name == "obs" else a
+
+    def terminal_ids(self) -> np.ndarray:
+        """Ids of the envs whose episode ended in the last step (sorted)."""
+        n = int(self.read_output("term_count")[0])
+        return np.sort(self.read_output("term_ids")[:n])
+
+    def _results(self):
+        if self.output == "torch":
+            t = self._t
+            return t["obs"], t["reward"], t["terminated"], t["truncated"]
+        return (self.read_output("obs"), self.read_output("reward64"),
+                self.read_output("terminated").astype(bool),
+                self.read_output("truncated").astype(bool))
+
+    # -- the Env API -------------------------------------------------------------------
+    def reset(self, seed=None, options=None, *, mask=None, inject_idx=None,
+              inject_position_index=None, inject_dataset=None):
+        """`TradingEnv.reset` (environments.py:163-199) for all envs, or those in `mask`.
+
+        `seed` is accepted for API compatibility; like in the reference (whose reset
+        draws from the global NumPy RNG) it does not reseed the episode draws — the
+        device Philox stream is keyed by the constructor's `seed`."""
+        def arr(a, dt):
+            if a is None:
+                return None, None
+            a = np.ascontiguousarray(np.asarray(a, dtype=dt))
+            if a.shape != (self.num_envs,):
+                raise ValueError(f"expected shape ({self.num_envs},), got {a.shape}")
+            return a, a.ctypes.data
+        m, mp = arr(mask, np.uint8)
+        a, ap = arr(inject_idx, np.int32)
+        b, bp = arr(inject_position_index, np.int32)
+        c, cp = arr(inject_dataset, np.int32)
+        _abi.check(self._lib, self._lib.gte_reset(self._h, mp, ap, bp, cp))
+        self._was_reset = True
+        return self._results()[0], LazyInfo(self)
+
+    def set_autoreset_injection(self, idx=None, position_index=None, dataset=None):
+        """Queue the draws of later auto-resets: i32 [N, n_episodes] arrays (parity runs)."""
+        arrs = [np.asarray(x) for x in (idx, position_index, dataset) if x is not None]
+        n = 0 if not arrs else arrs[0].reshape(self.num_envs, -1).shape[1]
+        def arr(a):
+            if a is None:
+                return None, None
+            a = np.ascontiguousarray(np.asarray(a, dtype=np.int32).reshape(self.num_envs, n))
+            return a, a.ctypes.data
+        a, ap = arr(idx)
+        b, bp = arr(position_index)
+        c, cp = arr(dataset)
+        _abi.check(self._lib, self._lib.gte_set_autoreset_injection(self._h, n, ap, bp, cp))
+
+    def step(self, actions):
+        """`TradingEnv.step` (environments.py:233-272) for every env in one launch.
+
+        actions: position indices, shape (N,); -1 (or None entries) = hold (:234).
+        A torch int32 CUDA tensor is used in place; anything else goes through a
+        host->device copy."""
+        torch = self._torch
+        if torch is not None and isinstance(actions, torch.Tensor) and actions.is_cuda:
+            if actions.dtype != torch.int32 or not actions.is_contiguous():
+                actions = actions.to(torch.int32).contiguous()
+            if actions.shape != (self.num_envs,):
+                raise ValueError(f"expected {self.num_envs} actions")
+            self._keep = actions  # keep alive until the launch has consumed it
+            _abi.check(self._lib, self._lib.gte_step(self._h, C.c_void_p(actions.data_ptr()), 1))
+        else:
+            if torch is not None and isinstance(actions, torch.Tensor):
+                actions = actions.cpu().numpy()
+            a = np.array([-1 if x is None else x for x in actions], dtype=np.int32) \
+                if isinstance(actions, (list, tuple)) else np.asarray(actions, dtype=np.int32)
+            a = np.ascontiguousarray(a)
+            if a.shape != (self.num_envs,):
+                raise ValueError(f"expected {self.num_envs} actions")
+            if a.size and (a.max() >= len(self.positions) or a.min() < -1):
+                raise IndexError("list index out of range")  # positions[position_index] (:234)
+            _abi.check(self._lib, self._lib.gte_step(self._h, a.ctypes.data, 0))
+        obs, reward, term, trunc = self._results()
+        return obs, reward, term, trunc, LazyInfo(self)
+
+    # -- misc ---------------------------------------------------------------------------
+    def synchronize(self):
+        _abi.check(self._lib, self._lib.gte_synchronize(self._h))
+
+    def launch_info(self) -> dict:
+        v = [C.c_int32() for _ in range(4)]
+        _abi.check(self._lib, self._lib.gte_get_launch_info(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("envs_per_wave", "threads_per_block", "n_blocks", "vector_bytes"),
+                        (x.value for x in v)))
+
+    def timer_start(self):
+        _abi.check(self._lib, self._lib.gte_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        _abi.check(self._lib, self._lib.gte_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.gte_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,483 @@
+// gte_api.hip — host side of libgte: the C ABI declared in include/gte.h.
+//
+// Owns the HBM-resident datasets, per-env state and outputs, validates the
+// arguments the way the reference constructor / reset do
+// (environments.py:79-125,163-199) and launches the kernels of
+// gte_kernels.hip.  No CPU path exists: without a gfx950 device every entry
+// point that needs one fails with GTE_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "gte_device.h"
+
+namespace gte {
+hipError_t launch_step(const Params& p, int vec, bool nt, int blocks, int threads,
+                       hipStream_t stream);
+hipError_t launch_reset(const Params& p, int vec, bool nt, int blocks, int threads,
+                        hipStream_t stream);
+}  // namespace gte
+
+using gte::DatasetDesc;
+using gte::Params;
+
+static thread_local std::string g_err = "";
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess)                                                         \
+      return fail(e_ == hipErrorOutOfMemory ? GTE_ERR_OOM : GTE_ERR_HIP,          \
+                  "%s failed: %s", #expr, hipGetErrorString(e_));                 \
+  } while (0)
+
+struct gte_env {
+  gte_config cfg;
+  Params p;
+  hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<void*> allocs;       // everything freed in gte_destroy
+  std::vector<DatasetDesc> h_ds;   // host copy of the descriptor table
+  std::vector<void*> ds_allocs[4]; // per dataset: feat, close, high, low
+  DatasetDesc* d_ds = nullptr;
+  gte_outputs owned;
+  // staging buffers for host-side arguments
+  int32_t* d_actions = nullptr;
+  uint8_t* d_mask = nullptr;
+  int32_t *d_inj_idx = nullptr, *d_inj_pos = nullptr, *d_inj_ds = nullptr;
+  int32_t *d_q_idx = nullptr, *d_q_pos = nullptr, *d_q_ds = nullptr;
+  bool finalized = false;
+  bool was_reset = false;
+  int vec = 1, blocks = 0, threads = 256;
+};
+
+template <typename T>
+static int dev_alloc(gte_env* E, T** out, size_t count, bool zero = true) {
+  void* ptr = nullptr;
+  size_t bytes = sizeof(T) * (count ? count : 1);
+  HIPCHK(hipMalloc(&ptr, bytes));
+  E->allocs.push_back(ptr);
+  if (zero) HIPCHK(hipMemset(ptr, 0, bytes));
+  *out = (T*)ptr;
+  return GTE_OK;
+}
+
+#define TRY(expr)            \
+  do {                       \
+    int rc_ = (expr);        \
+    if (rc_ != GTE_OK) return rc_; \
+  } while (0)
+
+static int validate(const gte_config* c) {
+  if (!c) return fail(GTE_ERR_INVALID, "config is NULL");
+  if (c->abi_version != GTE_ABI_VERSION || c->struct_bytes != (int32_t)sizeof(gte_config))
+    return fail(GTE_ERR_INVALID, "ABI mismatch: header version %d / %d bytes, library %d / %zu",
+                c->abi_version, c->struct_bytes, GTE_ABI_VERSION, sizeof(gte_config));
+  if (c->n_envs <= 0) return fail(GTE_ERR_INVALID, "n_envs must be > 0");
+  if (c->n_datasets <= 0) return fail(GTE_ERR_INVALID, "n_datasets must be > 0");
+  if (c->n_static < 0 || c->n_dyn < 0 || c->n_dyn > GTE_MAX_DYN)
+    return fail(GTE_ERR_INVALID, "n_static >= 0 and 0 <= n_dyn <= %d required", GTE_MAX_DYN);
+  if (c->n_static + c->n_dyn <= 0) return fail(GTE_ERR_INVALID, "observation has no columns");
+  if (c->n_static + c->n_dyn > 2048) return fail(GTE_ERR_INVALID, "F_obs > 2048 unsupported");
+  for (int i = 0; i < c->n_dyn; ++i)
+    if (c->dyn_kind[i] != GTE_DYN_LAST_POSITION && c->dyn_kind[i] != GTE_DYN_REAL_POSITION)
+      return fail(GTE_ERR_INVALID, "dyn_kind[%d] = %d unknown", i, c->dyn_kind[i]);
+  if (c->window < 0) return fail(GTE_ERR_INVALID, "window must be >= 0");
+  const int64_t W = c->window > 0 ? c->window : 1;
+  if (W * (c->n_static + c->n_dyn) > (1 << 18))
+    return fail(GTE_ERR_INVALID, "window * F_obs > 2^18 floats unsupported");
+  if (c->n_positions <= 0 || c->n_positions > GTE_MAX_POSITIONS)
+    return fail(GTE_ERR_INVALID, "1..%d positions required", GTE_MAX_POSITIONS);
+  if (c->initial_position_index < -1 || c->initial_position_index >= c->n_positions)
+    return fail(GTE_ERR_INVALID,
+                "The 'initial_position' parameter must be 'random' or a position mentionned "
+                "in the 'position' parameter.");  // environments.py:106
+  if (c->max_episode_duration < 0 || c->max_episode_duration == 1)
+    return fail(GTE_ERR_INVALID, "max_episode_duration must be 0 ('max') or >= 2");
+  if (!(c->portfolio_initial_value > 0.0))
+    return fail(GTE_ERR_INVALID, "portfolio_initial_value must be > 0");
+  if (c->reward_kind < 0 || c->reward_kind > GTE_REWARD_CLIPPED_LOG_RETURN)
+    return fail(GTE_ERR_INVALID, "reward_kind %d unknown", c->reward_kind);
+  if (c->autoreset < 0 || c->autoreset > GTE_AUTORESET_SAME_STEP)
+    return fail(GTE_ERR_INVALID, "autoreset %d unknown", c->autoreset);
+  if (c->episodes_between_dataset_switch < 1)
+    return fail(GTE_ERR_INVALID, "episodes_between_dataset_switch must be >= 1");
+  if (c->envs_per_wave != 0 &&
+      (c->envs_per_wave < 1 || c->envs_per_wave > 64 || (c->envs_per_wave & (c->envs_per_wave - 1))))
+    return fail(GTE_ERR_INVALID, "envs_per_wave must be 0 or a power of two <= 64");
+  return GTE_OK;
+}
+
+static int require_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(GTE_ERR_NO_DEVICE,
+                "no HIP device available (%s): libgte has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+  if (device < 0 || device >= n)
+    return fail(GTE_ERR_NO_DEVICE, "device %d out of range (have %d)", device, n);
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(GTE_ERR_NO_DEVICE, "device %d is %s; libgte is built for gfx950 (MI355X) only",
+                device, prop.gcnArchName);
+  return GTE_OK;
+}
+
+extern "C" {
+
+int gte_abi_version(void) { return GTE_ABI_VERSION; }
+
+const char* gte_last_error(void) { return g_err.c_str(); }
+
+int gte_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int gte_create(const gte_config* cfg, gte_env** out) {
+  if (!out) return fail(GTE_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  TRY(validate(cfg));
+  TRY(require_device(cfg->device));
+  HIPCHK(hipSetDevice(cfg->device));
+  gte_env* E = new (std::nothrow) gte_env();
+  if (!E) return fail(GTE_ERR_OOM, "host allocation failed");
+  E->cfg = *cfg;
+  memset(&E->p, 0, sizeof(Params));
+  memset(&E->owned, 0, sizeof(gte_outputs));
+  Params& p = E->p;
+  p.N = cfg->n_envs;
+  p.D = cfg->n_datasets;
+  p.Fs = cfg->n_static;
+  p.nd = cfg->n_dyn;
+  p.Fobs = p.Fs + p.nd;
+  p.has_window = cfg->window > 0;
+  p.W = p.has_window ? cfg->window : 1;
+  p.P = cfg->n_positions;
+  for (int i = 0; i < GTE_MAX_DYN; ++i) p.dyn_kind[i] = cfg->dyn_kind[i];
+  p.init_pos_index = cfg->initial_position_index;
+  p.max_dur = cfg->max_episode_duration;
+  p.reward_kind = cfg->reward_kind;
+  p.autoreset = cfg->autoreset;
+  p.switch_every = cfg->episodes_between_dataset_switch;
+  p.persist = cfg->dyn_persist ? 1 : 0;
+  p.fees = cfg->trading_fees;
+  p.rate = cfg->borrow_interest_rate;
+  p.V0 = cfg->portfolio_initial_value;
+  p.rp0 = cfg->reward_param0;
+  p.rp1 = cfg->reward_param1;
+  p.rp2 = cfg->reward_param2;
+  p.seed = cfg->seed;
+  p.env_id_base = cfg->env_id_base;
+
+  int rc = GTE_OK;
+  auto chk = [&](int r) { if (rc == GTE_OK) rc = r; };
+  const size_t N = (size_t)p.N;
+  chk(hipStreamCreateWithFlags(&E->own_stream, hipStreamNonBlocking) == hipSuccess
+          ? GTE_OK : fail(GTE_ERR_HIP, "hipStreamCreate failed"));
+  E->stream = E->own_stream;
+  chk(hipEventCreate(&E->ev0) == hipSuccess && hipEventCreate(&E->ev1) == hipSuccess
+          ? GTE_OK : fail(GTE_ERR_HIP, "hipEventCreate failed"));
+  chk(dev_alloc(E, &p.idx, N)); chk(dev_alloc(E, &p.step, N)); chk(dev_alloc(E, &p.pos, N));
+  chk(dev_alloc(E, &p.dsi, N)); chk(dev_alloc(E, &p.start, N)); chk(dev_alloc(E, &p.episode, N));
+  chk(dev_alloc(E, &p.needs_reset, N)); chk(dev_alloc(E, &p.eps_on_ds, N));
+  chk(dev_alloc(E, &p.n_picks, N)); chk(dev_alloc(E, &p.q_head, N));
+  chk(dev_alloc(E, &p.asset, N)); chk(dev_alloc(E, &p.fiat, N)); chk(dev_alloc(E, &p.ia, N));
+  chk(dev_alloc(E, &p.ifi, N)); chk(dev_alloc(E, &p.pv, N)); chk(dev_alloc(E, &p.realpos, N));
+  chk(dev_alloc(E, &E->owned.obs, N * p.W * p.Fobs));
+  chk(dev_alloc(E, &E->owned.reward, N)); chk(dev_alloc(E, &E->owned.reward64, N));
+  chk(dev_alloc(E, &E->owned.terminated, N)); chk(dev_alloc(E, &E->owned.truncated, N));
+  chk(dev_alloc(E, &E->owned.term_count, 1)); chk(dev_alloc(E, &E->owned.term_ids, N));
+  chk(dev_alloc(E, &E->d_actions, N)); chk(dev_alloc(E, &E->d_mask, N));
+  chk(dev_alloc(E, &E->d_inj_idx, N)); chk(dev_alloc(E, &E->d_inj_pos, N));
+  chk(dev_alloc(E, &E->d_inj_ds, N));
+  double* d_pos = nullptr;
+  chk(dev_alloc(E, &d_pos, GTE_MAX_POSITIONS));
+  chk(dev_alloc(E, &E->d_ds, (size_t)p.D));
+  if (rc == GTE_OK &&
+      hipMemcpy(d_pos, cfg->positions, sizeof(double) * p.P, hipMemcpyHostToDevice) != hipSuccess)
+    rc = fail(GTE_ERR_HIP, "copying positions failed");
+  if (rc != GTE_OK) {
+    std::string keep = g_err;
+    gte_destroy(E);
+    g_err = keep;
+    return rc;
+  }
+  p.positions = d_pos;
+  p.ds = E->d_ds;
+  E->owned.obs_elems_per_env = (int64_t)p.W * p.Fobs;
+  p.obs = E->owned.obs; p.reward = E->owned.reward; p.reward64 = E->owned.reward64;
+  p.terminated = E->owned.terminated; p.truncated = E->owned.truncated;
+  p.term_count = E->owned.term_count; p.term_ids = E->owned.term_ids;
+  E->h_ds.assign((size_t)p.D, DatasetDesc{nullptr, nullptr, nullptr, nullptr, 0});
+  for (auto& v : E->ds_allocs) v.assign((size_t)p.D, nullptr);
+
+  // launch geometry: EPW environments per wavefront, 4 wavefronts per workgroup
+  E->vec = (p.Fobs % 4 == 0) ? 4 : 1;
+  const int64_t vpe = (int64_t)p.W * p.Fobs / E->vec;  // vectors per env
+  int epw = cfg->envs_per_wave;
+  if (epw == 0) {
+    epw = 64;
+    // enough wavefronts to fill 256 CUs x 16 waves ...
+    while (epw > 1 && ((int64_t)p.N + epw - 1) / epw < 4096) epw >>= 1;
+    // ... but at least 256 vectors of copy work per wavefront
+    while (epw < 64 && (int64_t)epw * vpe < 256) epw <<= 1;
+  }
+  while (epw > 1 && (int64_t)epw * vpe > (1 << 20)) epw >>= 1;  // keeps the index math in range
+  p.epw = epw;
+  const int64_t waves = ((int64_t)p.N + epw - 1) / epw;
+  E->threads = 256;
+  E->blocks = (int)((waves + 3) / 4);
+  // the zero-fills above ran on the null stream; the env's stream is non-blocking
+  if (hipDeviceSynchronize() != hipSuccess) {
+    gte_destroy(E);
+    return fail(GTE_ERR_HIP, "hipDeviceSynchronize failed after allocation");
+  }
+  *out = E;
+  return GTE_OK;
+}
+
+int gte_upload_dataset(gte_env* E, int32_t d, const float* feat, const double* close,
+                       const double* high, const double* low, int64_t T) {
+  if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
+  const Params& p = E->p;
+  if (d < 0 || d >= p.D) return fail(GTE_ERR_INVALID, "dataset index %d out of range", d);
+  if (!feat || !close) return fail(GTE_ERR_INVALID, "feat and close are required");
+  if (T <= 0 || T > 0x7FFFFFF0ll) return fail(GTE_ERR_INVALID, "T out of range");
+  // the conditions under which the reference's reset/step are defined (:171-177)
+  const int64_t idx0 = p.has_window ? p.W - 1 : 0;
+  if (T < idx0 + 2) return fail(GTE_ERR_INVALID, "dataset of %lld rows is too short for windows=%d",
+                                (long long)T, p.W);
+  if (p.max_dur > 0 && T - p.max_dur - idx0 <= idx0)
+    return fail(GTE_ERR_INVALID, "low >= high: %lld rows cannot host episodes of %d steps",
+                (long long)T, p.max_dur);
+  if (E->finalized && p.persist && T > p.depth)
+    return fail(GTE_ERR_STATE, "dyn_persist: cannot upload a longer dataset after the first reset");
+  HIPCHK(hipSetDevice(E->cfg.device));
+  HIPCHK(hipStreamSynchronize(E->stream));
+  const void* srcs[4] = {feat, close, high, low};
+  const size_t bytes[4] = {sizeof(float) * (size_t)T * p.Fobs, sizeof(double) * (size_t)T,
+                           sizeof(double) * (size_t)T, sizeof(double) * (size_t)T};
+  void* dev[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int k = 0; k < 4; ++k) {
+    if (E->ds_allocs[k][d]) { (void)hipFree(E->ds_allocs[k][d]); E->ds_allocs[k][d] = nullptr; }
+    if (!srcs[k]) continue;
+    HIPCHK(hipMalloc(&dev[k], bytes[k]));
+    E->ds_allocs[k][d] = dev[k];
+    HIPCHK(hipMemcpy(dev[k], srcs[k], bytes[k], hipMemcpyHostToDevice));
+  }
+  E->h_ds[d] = DatasetDesc{(const float*)dev[0], (const double*)dev[1], (const double*)dev[2],
+                           (const double*)dev[3], T};
+  HIPCHK(hipMemcpy(E->d_ds, E->h_ds.data(), sizeof(DatasetDesc) * p.D, hipMemcpyHostToDevice));
+  return GTE_OK;
+}
+
+static int finalize(gte_env* E) {
+  if (E->finalized) return GTE_OK;
+  Params& p = E->p;
+  int64_t maxT = 0;
+  for (int d = 0; d < p.D; ++d) {
+    if (E->h_ds[d].T <= 0) return fail(GTE_ERR_STATE, "dataset %d was never uploaded", d);
+    if (E->h_ds[d].T > maxT) maxT = E->h_ds[d].T;
+  }
+  p.depth = p.persist ? maxT : p.W;
+  TRY(dev_alloc(E, &p.ring, (size_t)p.N * p.depth * (p.nd ? p.nd : 1)));
+  HIPCHK(hipDeviceSynchronize());
+  E->finalized = true;
+  return GTE_OK;
+}
+
+static int stage(gte_env* E, void* dst, const void* src, size_t bytes) {
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, E->stream));
+  return GTE_OK;
+}
+
+int gte_reset(gte_env* E, const uint8_t* mask, const int32_t* inj_idx,
+              const int32_t* inj_pos_index, const int32_t* inj_dataset) {
+  if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
+  HIPCHK(hipSetDevice(E->cfg.device));
+  TRY(finalize(E));
+  Params p = E->p;
+  const size_t N = (size_t)p.N;
+  p.mask = nullptr; p.inj_idx = p.inj_pos = p.inj_ds = nullptr;
+  if (mask) { TRY(stage(E, E->d_mask, mask, N)); p.mask = E->d_mask; }
+  if (inj_idx) { TRY(stage(E, E->d_inj_idx, inj_idx, 4 * N)); p.inj_idx = E->d_inj_idx; }
+  if (inj_pos_index) { TRY(stage(E, E->d_inj_pos, inj_pos_index, 4 * N)); p.inj_pos = E->d_inj_pos; }
+  if (inj_dataset) { TRY(stage(E, E->d_inj_ds, inj_dataset, 4 * N)); p.inj_ds = E->d_inj_ds; }
+  HIPCHK(hipMemsetAsync(p.term_count, 0, sizeof(int32_t), E->stream));
+  HIPCHK(gte::launch_reset(p, E->vec, E->cfg.nontemporal_obs != 0, E->blocks, E->threads, E->stream));
+  // host staging buffers may be reused by the caller right away: pageable copies above
+  // are complete on return, but keep the contract simple and explicit
+  HIPCHK(hipStreamSynchronize(E->stream));
+  E->was_reset = true;
+  return GTE_OK;
+}
+
+int gte_set_autoreset_injection(gte_env* E, int32_t n, const int32_t* inj_idx,
+                                const int32_t* inj_pos_index, const int32_t* inj_dataset) {
+  if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
+  if (n < 0) return fail(GTE_ERR_INVALID, "n_episodes must be >= 0");
+  HIPCHK(hipSetDevice(E->cfg.device));
+  HIPCHK(hipStreamSynchronize(E->stream));
+  Params& p = E->p;
+  const size_t count = (size_t)p.N * (size_t)n;
+  auto put = [&](int32_t** slot, const int32_t* src, const int32_t** param) -> int {
+    *param = nullptr;
+    if (!src || n == 0) return GTE_OK;
+    int32_t* dev = nullptr;
+    TRY(dev_alloc(E, &dev, count, false));  // released in gte_destroy
+    HIPCHK(hipMemcpy(dev, src, sizeof(int32_t) * count, hipMemcpyHostToDevice));
+    *slot = dev;
+    *param = dev;
+    return GTE_OK;
+  };
+  TRY(put(&E->d_q_idx, inj_idx, &p.q_idx));
+  TRY(put(&E->d_q_pos, inj_pos_index, &p.q_pos));
+  TRY(put(&E->d_q_ds, inj_dataset, &p.q_ds));
+  p.q_n = n;
+  HIPCHK(hipMemset(p.q_head, 0, sizeof(int32_t) * p.N));
+  HIPCHK(hipDeviceSynchronize());
+  return GTE_OK;
+}
+
+int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
+  if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
+  if (!E->was_reset) return fail(GTE_ERR_STATE, "gte_step before gte_reset");
+  if (!actions) return fail(GTE_ERR_INVALID, "actions is NULL");
+  Params p = E->p;
+  if (actions_on_device) {
+    p.actions = actions;
+  } else {
+    TRY(stage(E, E->d_actions, actions, sizeof(int32_t) * (size_t)p.N));
+    p.actions = E->d_actions;
+  }
+  HIPCHK(hipMemsetAsync(p.term_count, 0, sizeof(int32_t), E->stream));
+  HIPCHK(gte::launch_step(p, E->vec, E->cfg.nontemporal_obs != 0, E->blocks, E->threads, E->stream));
+  return GTE_OK;
+}
+
+int gte_get_outputs(gte_env* E, gte_outputs* out) {
+  if (!E || !out) return fail(GTE_ERR_INVALID, "NULL argument");
+  const Params& p = E->p;
+  out->obs = p.obs; out->reward = p.reward; out->reward64 = p.reward64;
+  out->terminated = p.terminated; out->truncated = p.truncated;
+  out->term_count = p.term_count; out->term_ids = p.term_ids;
+  out->obs_elems_per_env = (int64_t)p.W * p.Fobs;
+  return GTE_OK;
+}
+
+int gte_bind_outputs(gte_env* E, const gte_outputs* b) {
+  if (!E || !b) return fail(GTE_ERR_INVALID, "NULL argument");
+  HIPCHK(hipStreamSynchronize(E->stream));
+  Params& p = E->p;
+  if (b->obs && ((uintptr_t)b->obs & 15)) return fail(GTE_ERR_INVALID, "obs must be 16-byte aligned");
+  p.obs = b->obs ? b->obs : E->owned.obs;
+  p.reward = b->reward ? b->reward : E->owned.reward;
+  p.reward64 = b->reward64 ? b->reward64 : E->owned.reward64;
+  p.terminated = b->terminated ? b->terminated : E->owned.terminated;
+  p.truncated = b->truncated ? b->truncated : E->owned.truncated;
+  p.term_count = b->term_count ? b->term_count : E->owned.term_count;
+  p.term_ids = b->term_ids ? b->term_ids : E->owned.term_ids;
+  return GTE_OK;
+}
+
+int gte_get_state(gte_env* E, gte_state_view* out) {
+  if (!E || !out) return fail(GTE_ERR_INVALID, "NULL argument");
+  const Params& p = E->p;
+  out->idx = p.idx; out->step = p.step; out->position_index = p.pos;
+  out->dataset_index = p.dsi; out->start_idx = p.start; out->episode = p.episode;
+  out->needs_reset = p.needs_reset; out->asset = p.asset; out->fiat = p.fiat;
+  out->interest_asset = p.ia; out->interest_fiat = p.ifi;
+  out->portfolio_valuation = p.pv; out->real_position = p.realpos;
+  return GTE_OK;
+}
+
+int gte_set_stream(gte_env* E, void* hip_stream) {
+  if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
+  HIPCHK(hipStreamSynchronize(E->stream));
+  E->stream = hip_stream ? (hipStream_t)hip_stream : E->own_stream;
+  return GTE_OK;
+}
+
+int gte_synchronize(gte_env* E) {
+  if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
+  HIPCHK(hipStreamSynchronize(E->stream));
+  return GTE_OK;
+}
+
+int gte_timer_start(gte_env* E) {
+  if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
+  HIPCHK(hipEventRecord(E->ev0, E->stream));
+  return GTE_OK;
+}
+
+int gte_timer_stop(gte_env* E, float* elapsed_ms) {
+  if (!E || !elapsed_ms) return fail(GTE_ERR_INVALID, "NULL argument");
+  HIPCHK(hipEventRecord(E->ev1, E->stream));
+  HIPCHK(hipEventSynchronize(E->ev1));
+  HIPCHK(hipEventElapsedTime(elapsed_ms, E->ev0, E->ev1));
+  return GTE_OK;
+}
+
+int gte_read_obs(gte_env* E, int32_t first_env, int32_t n, float* host_dst) {
+  if (!E || !host_dst) return fail(GTE_ERR_INVALID, "NULL argument");
+  const Params& p = E->p;
+  if (first_env < 0 || n < 0 || (int64_t)first_env + n > p.N)
+    return fail(GTE_ERR_INVALID, "env range [%d, %d) out of [0, %d)", first_env, first_env + n, p.N);
+  const size_t per = (size_t)p.W * p.Fobs;
+  HIPCHK(hipStreamSynchronize(E->stream));
+  HIPCHK(hipMemcpy(host_dst, p.obs + per * first_env, sizeof(float) * per * n, hipMemcpyDeviceToHost));
+  return GTE_OK;
+}
+
+int gte_copy_to_host(gte_env* E, const void* device_src, void* host_dst, uint64_t bytes) {
+  if (!E || !device_src || !host_dst) return fail(GTE_ERR_INVALID, "NULL argument");
+  HIPCHK(hipStreamSynchronize(E->stream));
+  HIPCHK(hipMemcpy(host_dst, device_src, (size_t)bytes, hipMemcpyDeviceToHost));
+  return GTE_OK;
+}
+
+int gte_get_launch_info(gte_env* E, int32_t* envs_per_wave, int32_t* threads_per_block,
+                        int32_t* n_blocks, int32_t* vector_bytes) {
+  if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
+  if (envs_per_wave) *envs_per_wave = E->p.epw;
+  if (threads_per_block) *threads_per_block = E->threads;
+  if (n_blocks) *n_blocks = E->blocks;
+  if (vector_bytes) *vector_bytes = E->vec * 4;
+  return GTE_OK;
+}
+
+void gte_destroy(gte_env* E) {
+  if (!E) return;
+  (void)hipSetDevice(E->cfg.device);
+  if (E->stream) (void)hipStreamSynchronize(E->stream);
+  for (void* ptr : E->allocs) (void)hipFree(ptr);
+  for (auto& v : E->ds_allocs)
+    for (void* ptr : v)
+      if (ptr) (void)hipFree(ptr);
+  if (E->ev0) (void)hipEventDestroy(E->ev0);
+  if (E->ev1) (void)hipEventDestroy(E->ev1);
+  if (E->own_stream) (void)hipStreamDestroy(E->own_stream);
+  delete E;
+}
+
+}  // extern "C"

@@ -198,8 +198,13 @@ int gte_synchronize(gte_env* env);
 int gte_timer_start(gte_env* env);
 int gte_timer_stop(gte_env* env, float* elapsed_ms); /* synchronises */
 
-/* Copies that the N=1 drop-in needs (synchronous, device -> host). */
+/* Synchronous device -> host copies (the N=1 drop-in and the tests use them;
+ * the batched path keeps everything on the device). */
 int gte_read_obs(gte_env* env, int32_t first_env, int32_t n, float* host_dst);
+/* device_src must be a pointer obtained from gte_get_outputs / gte_get_state
+ * (plus an offset inside that array); waits for the env's stream first. */
+int gte_copy_to_host(gte_env* env, const void* device_src, void* host_dst,
+                     uint64_t bytes);
 
 /* kernel geometry actually used (for DESIGN.md / bench output) */
 int gte_get_launch_info(gte_env* env, int32_t* envs_per_wave,

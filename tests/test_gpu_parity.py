@@ -1,0 +1,189 @@
+"""Parity of the HIP path (through the C ABI) with (a) the golden traces captured
+from the reference and (b) the oracle on seeded random inputs.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+import replay
+from gym_trading_env_amd.config import make_config
+
+pytestmark = pytest.mark.gpu
+
+
+class GpuAdapter:
+    """BatchedTradingEnv behind the replay interface; every value read back through
+    the C ABI (gte_copy_to_host), no torch involved."""
+
+    def __init__(self, g, tile=1, **over):
+        from gym_trading_env_amd.batched import BatchedTradingEnv
+        kw = replay.config_kwargs(g, tile, **over)
+        n_envs = kw.pop("n_envs")
+        kw.pop("n_static"); kw.pop("n_datasets")
+        self.env = BatchedTradingEnv(list(g["datasets"]) if len(g["datasets"]) > 1 else g["datasets"][0],
+                                     num_envs=n_envs, output="numpy", **kw)
+
+    def reset(self, mask, idx, pos, ds):
+        self.env.reset(mask=mask, inject_idx=idx, inject_position_index=pos, inject_dataset=ds)
+
+    def set_autoreset_injection(self, idx, pos, ds):
+        self.env.set_autoreset_injection(idx, pos, ds)
+
+    def step(self, actions):
+        self.env.step(np.asarray(actions, np.int32))
+
+    obs = lambda s: s.env.read_output("obs")
+    reward64 = lambda s: s.env.read_output("reward64")
+    terminated = lambda s: s.env.read_output("terminated")
+    truncated = lambda s: s.env.read_output("truncated")
+
+    def state(self):
+        names = ("idx", "step", "position_index", "dataset_index", "asset", "fiat",
+                 "interest_asset", "interest_fiat", "portfolio_valuation", "real_position")
+        return {n: self.env.state(n) for n in names}
+
+
+@pytest.mark.parametrize("name", replay.golden_names())
+def test_hip_matches_reference_trace(name):
+    """idx/step/position/done/truncated bit-exact; fp64 portfolio state, rewards and
+    observations against the reference's own outputs (north-star tolerance: 1e-6
+    relative; measured: state bit-exact, reward <= 1 ulp of f64)."""
+    g = replay.load(name)
+    if g["op"].shape[0] > 700:  # keep per-call D2H round trips bounded
+        for k in list(g):
+            if isinstance(g[k], np.ndarray) and g[k].ndim >= 2 and g[k].shape[0] == g["op"].shape[0]:
+                g[k] = g[k][:700]
+    a = GpuAdapter(g)
+    worst = replay.replay(a, g, rtol=1e-12)
+    assert worst <= 1e-12
+    a.env.close()
+
+
+@pytest.mark.parametrize("name,epw", [("c3_window20", 1), ("c3_window20", 4), ("c2_nowindow", 64),
+                                      ("drawdown_done", 2), ("multidataset_k1", 8)])
+def test_hip_trace_tiled_across_waves(name, epw):
+    """Same traces, envs tiled 67x so that they span many wavefronts / workgroups and a
+    ragged last wave, for several envs-per-wave geometries."""
+    g = replay.load(name)
+    K = min(g["op"].shape[0], 160)
+    for k in list(g):
+        if isinstance(g[k], np.ndarray) and g[k].ndim >= 2 and g[k].shape[0] == g["op"].shape[0]:
+            g[k] = g[k][:K]
+    a = GpuAdapter(g, tile=67, envs_per_wave=epw)
+    replay.replay(a, g, tile=67, rtol=1e-12)
+    a.env.close()
+
+
+def _synthetic(seed, T, n_static, sigma=5e-3, drift=0.0):
+    rng = np.random.default_rng(seed)
+    close = 100.0 * np.exp(np.cumsum(rng.normal(drift, sigma, T)))
+    feat = rng.normal(0, 1, (T, n_static)).astype(np.float32)
+    return feat, close
+
+
+def _compare_with_oracle(oracle_mod, datasets, n_envs, steps, seed, check_every=1, **kw):
+    """Drive the HIP env and the oracle with the same config, the same device-RNG
+    seed (no injection: Philox draws on both sides) and the same actions."""
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    env = BatchedTradingEnv(datasets if len(datasets) > 1 else datasets[0], num_envs=n_envs,
+                            output="numpy", seed=seed, **kw)
+    n_dyn = env.cfg.n_dyn
+    staged = []
+    for f, c in datasets:
+        full = np.zeros((f.shape[0], f.shape[1] + n_dyn), np.float32)
+        full[:, :f.shape[1]] = f
+        staged.append((full, c))
+    ora = oracle_mod.OracleEnv(env.cfg, staged)
+    env.reset()
+    ora.reset()
+    rng = np.random.default_rng(seed + 1)
+    P = len(env.positions)
+    names_i = ("idx", "step", "position_index", "dataset_index", "start_idx", "episode", "needs_reset")
+    names_f = ("asset", "fiat", "interest_asset", "interest_fiat", "portfolio_valuation", "real_position")
+    n_term = 0
+    for k in range(steps + 1):
+        if k > 0:
+            a = rng.integers(-1, P, n_envs).astype(np.int32)
+            env.step(a)
+            ora.step(a, threads=8)
+        if k % check_every and k != steps:
+            continue
+        so = ora.state()
+        for n in names_i:
+            np.testing.assert_array_equal(env.state(n), so[n], err_msg=f"step {k} {n}")
+        for n in names_f:
+            np.testing.assert_allclose(env.state(n), so[n], rtol=1e-12, atol=0, err_msg=f"step {k} {n}")
+        np.testing.assert_array_equal(env.read_output("terminated"), ora.terminated, err_msg=f"step {k}")
+        np.testing.assert_array_equal(env.read_output("truncated"), ora.truncated, err_msg=f"step {k}")
+        # device log() vs libm log(): <= 1 ulp of f64 each
+        np.testing.assert_allclose(env.read_output("reward64"), ora.reward64, rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(env.read_output("reward"), ora.reward, rtol=1e-6, atol=1e-12)
+        np.testing.assert_array_equal(env.read_output("obs"), ora.obs, err_msg=f"step {k} obs")
+        if k > 0:
+            np.testing.assert_array_equal(env.terminal_ids(), np.sort(ora.term_ids))
+            n_term += len(ora.term_ids)
+    env.close()
+    ora.close()
+    return n_term
+
+
+@pytest.mark.parametrize("autoreset", ["next_step", "same_step", None])
+def test_hip_vs_oracle_c3_shape_random_resets(oracle_mod, autoreset):
+    ds = [_synthetic(11, 700, 30, sigma=2e-2)]
+    n = _compare_with_oracle(oracle_mod, ds, n_envs=3000, steps=150, seed=5, windows=20,
+                             positions=[-1, 0, 1], trading_fees=1e-4, borrow_interest_rate=3e-6,
+                             max_episode_duration=40, autoreset=autoreset)
+    assert n > 3000  # every env ended at least once
+
+
+def test_hip_vs_oracle_c2_shape(oracle_mod):
+    ds = [_synthetic(12, 500, 14)]
+    _compare_with_oracle(oracle_mod, ds, n_envs=4096, steps=120, seed=6, positions=[-1, 0, 1],
+                         trading_fees=1e-4, borrow_interest_rate=3e-6, max_episode_duration=50,
+                         autoreset="next_step")
+
+
+@pytest.mark.parametrize("n_static,windows", [(3, 7), (1, None), (17, 3), (0, 5), (30, 20)])
+def test_hip_vs_oracle_odd_shapes(oracle_mod, n_static, windows):
+    """F_obs not a multiple of 4 takes the 4-byte path; ragged last wave (N=1001)."""
+    ds = [_synthetic(13, 300, n_static, sigma=3e-2, drift=-2e-3)]
+    _compare_with_oracle(oracle_mod, ds, n_envs=1001, steps=100, seed=7, windows=windows,
+                         positions=[-2, -1, 0, 0.5, 1, 2], trading_fees=1e-3,
+                         borrow_interest_rate=1e-4, autoreset="next_step")
+
+
+@pytest.mark.parametrize("switch,persist", [(1, False), (2, True)])
+def test_hip_vs_oracle_multidataset(oracle_mod, switch, persist):
+    ds = [_synthetic(100 + d, 150 + 13 * d, 6) for d in range(9)]
+    _compare_with_oracle(oracle_mod, ds, n_envs=777, steps=160, seed=8, windows=4,
+                         positions=[-1, 0, 1], trading_fees=1e-4, max_episode_duration=25,
+                         episodes_between_dataset_switch=switch, dyn_persist=persist,
+                         autoreset="next_step")
+
+
+def test_hip_vs_oracle_persist_single_dataset(oracle_mod):
+    ds = [_synthetic(21, 200, 2)]
+    _compare_with_oracle(oracle_mod, ds, n_envs=300, steps=200, seed=9, windows=6,
+                         positions=[-1, 0, 1], max_episode_duration=20, dyn_persist=True,
+                         autoreset="same_step")
+
+
+def test_hip_masked_reset_and_disabled_autoreset(oracle_mod):
+    """Caller-driven resets with a mask; other envs must be untouched."""
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    f, c = _synthetic(31, 120, 4)
+    kw = dict(positions=[0, 1], windows=3, max_episode_duration=30, autoreset=None, seed=3)
+    env = BatchedTradingEnv((f, c), num_envs=500, output="numpy", **kw)
+    full = np.zeros((120, 6), np.float32); full[:, :4] = f
+    ora = oracle_mod.OracleEnv(env.cfg, [(full, c)])
+    env.reset(); ora.reset()
+    rng = np.random.default_rng(0)
+    for k in range(80):
+        a = rng.integers(0, 2, 500).astype(np.int32)
+        env.step(a); ora.step(a)
+        if k % 10 == 9:
+            mask = (ora.truncated | ora.terminated).astype(np.uint8)
+            if mask.any():
+                env.reset(mask=mask); ora.reset(mask=mask)
+        np.testing.assert_array_equal(env.read_output("obs"), ora.obs)
+        np.testing.assert_array_equal(env.state("idx"), ora.state()["idx"])
+        np.testing.assert_array_equal(env.state("episode"), ora.state()["episode"])
+    env.close()
