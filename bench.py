@@ -61,13 +61,26 @@ def env_kwargs(wl):
                 autoreset="next_step")
 
 
+def host_cores() -> int:
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota
+    (a 1-GPU box exposes all host CPUs in the mask but only a 16-core share)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return int(os.environ.get("GTE_BENCH_CORES", min(n, 16)))
+
+
 def cpu_baseline(wl, seconds_target: float = 12.0):
     """Time the ORACLE (oracle/gte_oracle.c, OpenMP over envs) on the host cores on a
     bounded sample of the same workload.  Reported baseline only; never the product."""
     from gym_trading_env_amd.config import make_config
     from oracle import oracle
     oracle.build()
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     n_envs, n_dyn = 65_536, 2
     feat, close = synthetic_dataset(0, wl["T"], wl["n_static"])
     full = np.zeros((wl["T"], wl["n_static"] + n_dyn), np.float32)
@@ -177,7 +190,7 @@ def main():
         el, ev_ms = float(t[0]), float(t[1])
 
     # episodes really end inside the timed region (auto-reset is part of the step)
-    episodes = int(env.state("episode").sum())
+    episodes = int(env.state("episode").sum()) - N  # beyond the initial reset
     info = env.launch_info()
     b_alg = algorithmic_bytes(W, F_obs, wl["n_static"], n_dyn)
     kernel_us = ev_ms * 1e3 / args.steps

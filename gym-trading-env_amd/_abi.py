@@ -163,6 +163,13 @@ def load_library(path: str | None = None) -> C.CDLL:
             f"{p} is missing: the HIP extension has not been built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
             "gym-trading-env_amd/csrc`). There is no CPU fallback for the env.")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; libgte needs the same SONAME.  Two
+    # HIP runtimes in one process do not share devices, so when torch is installed load
+    # it FIRST: the dynamic linker then binds libgte to the runtime torch uses.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(p)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol

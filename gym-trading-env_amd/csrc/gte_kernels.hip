@@ -187,6 +187,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
         // the batch leaves such an env frozen, flags still raised
         p.reward[e] = 0.0f; p.reward64[e] = 0.0;
         stepped = false;
+        ended = true;  // its flags stay raised, so it stays in the terminal list
       }
     }
     if (stepped) {
