@@ -97,7 +97,7 @@ def cpu_baseline(wl, seconds_target: float = 12.0):
         env.step(acts[steps % 32], threads=cores)
         steps += 1
         el = time.perf_counter() - t0
-        if el > seconds_target or steps >= 4000:
+        if el > seconds_target or steps >= 20000:
             break
     env.close()
     return {"value": n_envs * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
@@ -113,7 +113,8 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's)")
     ap.add_argument("--epw", type=int, default=0, help="envs per wavefront (0 = auto)")
-    ap.add_argument("--nt", type=int, default=0, help="1: non-temporal observation stores")
+    ap.add_argument("--nt", type=int, default=1, help="non-temporal observation stores (default 1)")
+    ap.add_argument("--gather", default="auto", choices=["auto", "flat", "rows"])
     ap.add_argument("--gather-obs", action="store_true", help="also all-gather observations (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -142,7 +143,8 @@ def main():
     feat, close = synthetic_dataset(0, wl["T"], wl["n_static"])
     env = BatchedTradingEnv((feat, close), num_envs=N, seed=20240607, env_id_base=rank * N,
                             device=local_rank, output="torch", envs_per_wave=args.epw,
-                            nontemporal_obs=bool(args.nt), **env_kwargs(wl))
+                            nontemporal_obs=bool(args.nt), gather_path=args.gather,
+                            **env_kwargs(wl))
     gen = torch.Generator(device=dev)
     gen.manual_seed(99 + rank)
     n_rows = 64

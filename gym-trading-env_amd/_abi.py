@@ -72,6 +72,8 @@ class GteConfig(C.Structure):
         ("env_id_base", C.c_int64),
         ("envs_per_wave", C.c_int32),
         ("nontemporal_obs", C.c_int32),
+        ("gather_path", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -87,6 +89,8 @@ class GteOutputs(C.Structure):
         ("term_count", C.c_void_p),
         ("term_ids", C.c_void_p),
         ("obs_elems_per_env", C.c_int64),
+        ("term_slot", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 

@@ -113,7 +113,7 @@ class BatchedTradingEnv:
                  name="Stock", render_mode="logs", *, autoreset="next_step",
                  episodes_between_dataset_switch=1, dyn_persist=False, seed=0,
                  env_id_base=0, device=0, output="torch", envs_per_wave=0,
-                 nontemporal_obs=False, library_path=None):
+                 nontemporal_obs=True, gather_path="auto", library_path=None):
         assert render_mode is None or render_mode in self.metadata["render_modes"]
         if output not in ("torch", "numpy"):
             raise ValueError("output must be 'torch' or 'numpy'")
@@ -145,7 +145,8 @@ class BatchedTradingEnv:
             initial_position=initial_position, max_episode_duration=max_episode_duration,
             autoreset=autoreset, episodes_between_dataset_switch=episodes_between_dataset_switch,
             dyn_persist=dyn_persist, seed=seed, env_id_base=env_id_base, device=device,
-            envs_per_wave=envs_per_wave, nontemporal_obs=nontemporal_obs)
+            envs_per_wave=envs_per_wave, nontemporal_obs=nontemporal_obs,
+            gather_path=gather_path)
         _abi.check(self._lib, self._lib.gte_create(C.byref(self.cfg), C.byref(self._h)))
 
         self.n_obs = first.n_static + n_dyn
@@ -193,7 +194,7 @@ class BatchedTradingEnv:
                 "reward64": torch.zeros(N, dtype=torch.float64, device=dev),
                 "terminated": torch.zeros(N, dtype=torch.bool, device=dev),
                 "truncated": torch.zeros(N, dtype=torch.bool, device=dev),
-                "term_count": torch.zeros(1, dtype=torch.int32, device=dev),
+                "term_count": torch.zeros(2, dtype=torch.int32, device=dev),  # two slots
                 "term_ids": torch.zeros(N, dtype=torch.int32, device=dev),
             }
             torch.cuda.synchronize(dev)
@@ -223,13 +224,14 @@ class BatchedTradingEnv:
         spec = {"obs": (np.float32, N * int(np.prod(self.obs_shape))),
                 "reward": (np.float32, N), "reward64": (np.float64, N),
                 "terminated": (np.uint8, N), "truncated": (np.uint8, N),
-                "term_count": (np.int32, 1), "term_ids": (np.int32, N)}[name]
+                "term_count": (np.int32, 2), "term_ids": (np.int32, N)}[name]
         a = self._to_host(getattr(self._out, name), *spec)
         return a.reshape((N,) + self.obs_shape) if name == "obs" else a
 
     def terminal_ids(self) -> np.ndarray:
         """Ids of the envs whose episode ended in the last step (sorted)."""
-        n = int(self.read_output("term_count")[0])
+        _abi.check(self._lib, self._lib.gte_get_outputs(self._h, C.byref(self._out)))
+        n = int(self.read_output("term_count")[self._out.term_slot])
         return np.sort(self.read_output("term_ids")[:n])
 
     def _results(self):
@@ -312,8 +314,11 @@ class BatchedTradingEnv:
     def launch_info(self) -> dict:
         v = [C.c_int32() for _ in range(4)]
         _abi.check(self._lib, self._lib.gte_get_launch_info(self._h, *[C.byref(x) for x in v]))
-        return dict(zip(("envs_per_wave", "threads_per_block", "n_blocks", "vector_bytes"),
-                        (x.value for x in v)))
+        d = dict(zip(("envs_per_wave", "threads_per_block", "n_blocks", "vector_bytes"),
+                     (x.value for x in v)))
+        rows_u, d["vector_bytes"] = divmod(d["vector_bytes"], 1000)
+        d["gather"] = f"rows(chunk={64 * rows_u} vectors)" if rows_u else "flat"
+        return d
 
     def timer_start(self):
         _abi.check(self._lib, self._lib.gte_timer_start(self._h))

@@ -17,9 +17,9 @@
 #include "gte_device.h"
 
 namespace gte {
-hipError_t launch_step(const Params& p, int vec, bool nt, int blocks, int threads,
+hipError_t launch_step(const Params& p, int vec, bool nt, int rows_u, int blocks, int threads,
                        hipStream_t stream);
-hipError_t launch_reset(const Params& p, int vec, bool nt, int blocks, int threads,
+hipError_t launch_reset(const Params& p, int vec, bool nt, int rows_u, int blocks, int threads,
                         hipStream_t stream);
 }  // namespace gte
 
@@ -65,6 +65,9 @@ struct gte_env {
   bool finalized = false;
   bool was_reset = false;
   int vec = 1, blocks = 0, threads = 256;
+  int rows_u = 0;          // 0: flat gather; 1..4: rows gather, chunk = 64*rows_u vectors
+  int32_t* term_base = nullptr;  // the two-slot terminal counter in use (owned or bound)
+  int term_slot = 0;       // slot the last launch added to
 };
 
 template <typename T>
@@ -206,7 +209,7 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   chk(dev_alloc(E, &E->owned.obs, N * p.W * p.Fobs));
   chk(dev_alloc(E, &E->owned.reward, N)); chk(dev_alloc(E, &E->owned.reward64, N));
   chk(dev_alloc(E, &E->owned.terminated, N)); chk(dev_alloc(E, &E->owned.truncated, N));
-  chk(dev_alloc(E, &E->owned.term_count, 1)); chk(dev_alloc(E, &E->owned.term_ids, N));
+  chk(dev_alloc(E, &E->owned.term_count, 2)); chk(dev_alloc(E, &E->owned.term_ids, N));
   chk(dev_alloc(E, &E->d_actions, N)); chk(dev_alloc(E, &E->d_mask, N));
   chk(dev_alloc(E, &E->d_inj_idx, N)); chk(dev_alloc(E, &E->d_inj_pos, N));
   chk(dev_alloc(E, &E->d_inj_ds, N));
@@ -227,7 +230,7 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   E->owned.obs_elems_per_env = (int64_t)p.W * p.Fobs;
   p.obs = E->owned.obs; p.reward = E->owned.reward; p.reward64 = E->owned.reward64;
   p.terminated = E->owned.terminated; p.truncated = E->owned.truncated;
-  p.term_count = E->owned.term_count; p.term_ids = E->owned.term_ids;
+  E->term_base = E->owned.term_count; p.term_ids = E->owned.term_ids;
   E->h_ds.assign((size_t)p.D, DatasetDesc{nullptr, nullptr, nullptr, nullptr, 0});
   for (auto& v : E->ds_allocs) v.assign((size_t)p.D, nullptr);
 
@@ -243,6 +246,15 @@ int gte_create(const gte_config* cfg, gte_env** out) {
     while (epw < 64 && (int64_t)epw * vpe < 256) epw <<= 1;
   }
   while (epw > 1 && (int64_t)epw * vpe > (1 << 20)) epw >>= 1;  // keeps the index math in range
+  // observation gather: "rows" needs 16-byte vectors and windows of >= 64 vectors
+  const bool rows_ok = E->vec == 4 && vpe >= 64;
+  if (cfg->gather_path == 2 && !rows_ok) {
+    gte_destroy(E);
+    return fail(GTE_ERR_INVALID, "gather_path=rows needs F_obs %% 4 == 0 and window*F_obs >= 256");
+  }
+  // auto = flat: measured faster than rows at the headline shape (57 vs 63 us per step,
+  // profiles/r01_tune.log) because every lane of every wave instruction is used
+  E->rows_u = (cfg->gather_path == 2) ? (int)((vpe + 63) / 64 > 4 ? 4 : (vpe + 63) / 64) : 0;
   p.epw = epw;
   const int64_t waves = ((int64_t)p.N + epw - 1) / epw;
   E->threads = 256;
@@ -323,8 +335,12 @@ int gte_reset(gte_env* E, const uint8_t* mask, const int32_t* inj_idx,
   if (inj_idx) { TRY(stage(E, E->d_inj_idx, inj_idx, 4 * N)); p.inj_idx = E->d_inj_idx; }
   if (inj_pos_index) { TRY(stage(E, E->d_inj_pos, inj_pos_index, 4 * N)); p.inj_pos = E->d_inj_pos; }
   if (inj_dataset) { TRY(stage(E, E->d_inj_ds, inj_dataset, 4 * N)); p.inj_ds = E->d_inj_ds; }
-  HIPCHK(hipMemsetAsync(p.term_count, 0, sizeof(int32_t), E->stream));
-  HIPCHK(gte::launch_reset(p, E->vec, E->cfg.nontemporal_obs != 0, E->blocks, E->threads, E->stream));
+  HIPCHK(hipMemsetAsync(E->term_base, 0, 2 * sizeof(int32_t), E->stream));
+  E->term_slot = 0;
+  p.term_count = E->term_base;
+  p.term_count_next = E->term_base + 1;
+  HIPCHK(gte::launch_reset(p, E->vec, E->cfg.nontemporal_obs != 0, E->rows_u, E->blocks, E->threads,
+                           E->stream));
   // host staging buffers may be reused by the caller right away: pageable copies above
   // are complete on return, but keep the contract simple and explicit
   HIPCHK(hipStreamSynchronize(E->stream));
@@ -370,8 +386,13 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
     TRY(stage(E, E->d_actions, actions, sizeof(int32_t) * (size_t)p.N));
     p.actions = E->d_actions;
   }
-  HIPCHK(hipMemsetAsync(p.term_count, 0, sizeof(int32_t), E->stream));
-  HIPCHK(gte::launch_step(p, E->vec, E->cfg.nontemporal_obs != 0, E->blocks, E->threads, E->stream));
+  // two-slot terminal counter: this launch adds to one slot (cleared by the previous
+  // launch or by gte_reset) and clears the other, so no memset sits between steps
+  E->term_slot ^= 1;
+  p.term_count = E->term_base + E->term_slot;
+  p.term_count_next = E->term_base + (E->term_slot ^ 1);
+  HIPCHK(gte::launch_step(p, E->vec, E->cfg.nontemporal_obs != 0, E->rows_u, E->blocks, E->threads,
+                          E->stream));
   return GTE_OK;
 }
 
@@ -380,8 +401,10 @@ int gte_get_outputs(gte_env* E, gte_outputs* out) {
   const Params& p = E->p;
   out->obs = p.obs; out->reward = p.reward; out->reward64 = p.reward64;
   out->terminated = p.terminated; out->truncated = p.truncated;
-  out->term_count = p.term_count; out->term_ids = p.term_ids;
+  out->term_count = E->term_base; out->term_ids = p.term_ids;
   out->obs_elems_per_env = (int64_t)p.W * p.Fobs;
+  out->term_slot = E->term_slot;
+  out->reserved0 = 0;
   return GTE_OK;
 }
 
@@ -395,7 +418,10 @@ int gte_bind_outputs(gte_env* E, const gte_outputs* b) {
   p.reward64 = b->reward64 ? b->reward64 : E->owned.reward64;
   p.terminated = b->terminated ? b->terminated : E->owned.terminated;
   p.truncated = b->truncated ? b->truncated : E->owned.truncated;
-  p.term_count = b->term_count ? b->term_count : E->owned.term_count;
+  E->term_base = b->term_count ? b->term_count : E->owned.term_count;  // i32 [2]
+  HIPCHK(hipMemset(E->term_base, 0, 2 * sizeof(int32_t)));
+  HIPCHK(hipDeviceSynchronize());
+  E->term_slot = 0;
   p.term_ids = b->term_ids ? b->term_ids : E->owned.term_ids;
   return GTE_OK;
 }
@@ -462,7 +488,7 @@ int gte_get_launch_info(gte_env* E, int32_t* envs_per_wave, int32_t* threads_per
   if (envs_per_wave) *envs_per_wave = E->p.epw;
   if (threads_per_block) *threads_per_block = E->threads;
   if (n_blocks) *n_blocks = E->blocks;
-  if (vector_bytes) *vector_bytes = E->vec * 4;
+  if (vector_bytes) *vector_bytes = E->vec * 4 + 1000 * E->rows_u;  // + 1000*rows_u
   return GTE_OK;
 }
 

@@ -45,7 +45,8 @@ struct Params {
   float* reward;
   double* reward64;
   uint8_t *terminated, *truncated;
-  int32_t* term_count;
+  int32_t* term_count;       // slot of the 2-slot counter this launch adds to
+  int32_t* term_count_next;  // the other slot: cleared by this launch for the next one
   int32_t* term_ids;
   // --- inputs of this launch
   const int32_t* actions;                      // step: i32 [N] (device)
@@ -57,8 +58,6 @@ struct Params {
   int32_t* q_head;
   // --- geometry
   int32_t epw;         // environments per wavefront
-  uint32_t fobs_magic; // ceil(2^32 / Fobs)   (VEC == 1 path)
-  uint32_t f4_magic;   // ceil(2^32 / (Fobs/4)) (VEC == 4 path)
 };
 
 // ---------------------------------------------------------------------------

@@ -256,30 +256,16 @@ __device__ inline void store_out(T* dst, const T& v) {
   else *dst = v;
 }
 
-// dynamic-column value of window row w, dynamic feature i, for the env whose job
-// fields are given (per lane)
-__device__ inline float dyn_value(const Params& p, const float* ring_e, int w, int i,
-                                  int32_t slot0, int32_t n_zero, const float cur[GTE_MAX_DYN]) {
-  if (w == p.W - 1) {  // current row: still in phase A's registers
-    float c = cur[0];
-#pragma unroll
-    for (int k = 1; k < GTE_MAX_DYN; ++k) c = (i == k) ? cur[k] : c;
-    return c;
-  }
-  if (w < n_zero) return 0.0f;
-  int32_t slot = slot0 + w;
-  if (!p.persist && slot >= p.W) slot -= p.W;
-  return ring_e[(int64_t)slot * p.nd + i];
-}
-
-struct JobBcast {  // job fields of the env a lane works on
+// job fields of the env a lane (flat path) or the whole wave (rows path) works on
+struct JobView {
   const float* src;
   int32_t slot0, n_zero, flags;
   float cur[GTE_MAX_DYN];
 };
 
-__device__ inline JobBcast shuffle_job(const ObsJob& job, int el) {
-  JobBcast b;
+// every lane reads the job of env `el` (per-lane el): ds_bpermute
+__device__ inline JobView shuffle_job(const ObsJob& job, int el) {
+  JobView b;
   const uint64_t a = (uint64_t)job.src;
   const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)a, el);
   const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(a >> 32), el);
@@ -292,24 +278,70 @@ __device__ inline JobBcast shuffle_job(const ObsJob& job, int el) {
   return b;
 }
 
-// Generic "flat" gather: the wave's n_env*VPE vectors form one index space, lane
-// l of iteration t handles vector t*64+l, so stores are fully contiguous 64*VEC*4
-// bytes per wave instruction whatever the window size (also for W*F_obs < 64
-// vectors, e.g. windows=None).  The env a lane works on differs per lane, so the
-// job fields arrive through ds_bpermute (__shfl).
+// the whole wave reads the job of env `el` (wave-uniform el): v_readlane -> SGPRs
+__device__ inline JobView broadcast_job(const ObsJob& job, int el) {
+  JobView b;
+  const uint64_t a = (uint64_t)job.src;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)a, el);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(a >> 32), el);
+  b.src = (const float*)(((uint64_t)hi << 32) | lo);
+  b.slot0 = __builtin_amdgcn_readlane(job.slot0, el);
+  b.n_zero = __builtin_amdgcn_readlane(job.n_zero, el);
+  b.flags = __builtin_amdgcn_readlane(job.flags, el);
+#pragma unroll
+  for (int i = 0; i < GTE_MAX_DYN; ++i)
+    b.cur[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(job.cur[i]), el));
+  return b;
+}
+
+// Overwrite the dynamic columns that vector `v` (columns col .. col+VEC-1 of window
+// row w) covers.  Every array index below is a compile-time constant after
+// unrolling: a run-time index into cur[] or v[] would put them in scratch memory
+// (one scratch store per observation store — measured as 2x WRITE_SIZE).
+template <int VEC, typename vec_t>
+__device__ inline void patch_dynamic(const Params& p, vec_t& v, const float* ring_e, int w,
+                                     int col, const JobView& jb) {
+  if (col + VEC <= p.Fs) return;  // all static columns
+  int32_t slot = jb.slot0 + w;
+  if (!p.persist && slot >= p.W) slot -= p.W;
+  const bool is_cur = (w == p.W - 1);          // current row: phase A's registers
+  const bool from_store = !is_cur && w >= jb.n_zero;  // else: never written -> 0
+#pragma unroll
+  for (int i = 0; i < GTE_MAX_DYN; ++i) {
+    if (i < p.nd) {
+      const int c = p.Fs + i - col;  // component of v that holds dynamic feature i
+      if (c >= 0 && c < VEC) {
+        float x = is_cur ? jb.cur[i] : 0.0f;
+        if (from_store) x = ring_e[(int64_t)slot * p.nd + i];
+        if (VEC == 1) {
+          v = x;
+        } else {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) v[k] = (c == k) ? x : v[k];
+        }
+      }
+    }
+  }
+}
+
+// "flat" gather — any shape.  The wave's n_env*VPE vectors form one index space,
+// lane l of iteration t handles vector t*64+l, so every wave instruction stores
+// 64*VEC*4 contiguous bytes whatever the window size (also when an env's window is
+// smaller than one wave instruction, e.g. windows=None).  The env differs per
+// lane, so the job fields travel through ds_bpermute.
 template <int VEC, bool NT, int U>
 __device__ inline void phase_b_flat(const Params& p, int wave_first, int n_env, int lane,
                                     const ObsJob& job, uint64_t vpe_magic, uint64_t fv_magic) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
   const uint32_t V = (uint32_t)(p.W * p.Fobs);
-  const uint32_t VPE = V / VEC;             // vectors per env
+  const uint32_t VPE = V / VEC;                // vectors per env
   const uint32_t FV = (uint32_t)p.Fobs / VEC;  // vectors per row
   const uint32_t total = (uint32_t)n_env * VPE;
   float* const obs0 = p.obs + (int64_t)wave_first * V;
 
   for (uint32_t k0 = 0; k0 < total; k0 += 64u * U) {
     vec_t v[U];
-    JobBcast jb[U];
+    JobView jb[U];
     uint32_t jj[U], ee[U];
     bool ok[U];
 #pragma unroll
@@ -317,10 +349,9 @@ __device__ inline void phase_b_flat(const Params& p, int wave_first, int n_env, 
       const uint32_t k = k0 + (uint32_t)u * 64u + (uint32_t)lane;
       const bool in = k < total;
       const uint32_t kk = in ? k : 0u;
-      const uint32_t el = fastdiv40(kk, vpe_magic);
-      jj[u] = kk - el * VPE;
-      ee[u] = el;
-      jb[u] = shuffle_job(job, (int)el);  // all lanes take part in the shuffles
+      ee[u] = fastdiv40(kk, vpe_magic);
+      jj[u] = kk - ee[u] * VPE;
+      jb[u] = shuffle_job(job, (int)ee[u]);  // all lanes take part in the shuffles
       ok[u] = in && (jb[u].flags & 1);
       if (ok[u]) v[u] = *(const vec_t*)(jb[u].src + (int64_t)jj[u] * VEC);
     }
@@ -328,22 +359,72 @@ __device__ inline void phase_b_flat(const Params& p, int wave_first, int n_env, 
     for (int u = 0; u < U; ++u) {
       if (!ok[u]) continue;
       const uint32_t k = k0 + (uint32_t)u * 64u + (uint32_t)lane;
-      const uint32_t el = ee[u];
       const uint32_t w = fastdiv40(jj[u], fv_magic);
       const int col = (int)(jj[u] - w * FV) * VEC;
-      if (col + VEC > p.Fs) {  // this vector overlaps the dynamic columns
-        const float* ring_e = p.ring + (int64_t)(wave_first + (int)el) * p.depth * p.nd;
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) {
-          const int i = col + c - p.Fs;
-          if (i >= 0) {
-            const float x = dyn_value(p, ring_e, (int)w, i, jb[u].slot0, jb[u].n_zero, jb[u].cur);
-            if (VEC == 1) v[u] = x; else v[u][c] = x;
-          }
-        }
-      }
+      const float* ring_e = p.ring + (int64_t)(wave_first + (int)ee[u]) * p.depth * p.nd;
+      patch_dynamic<VEC>(p, v[u], ring_e, (int)w, col, jb[u]);
       store_out<NT>((vec_t*)(obs0 + (int64_t)k * VEC), v[u]);
     }
+  }
+}
+
+// "rows" gather — windows of at least one wave instruction (VPE >= 64 vectors).
+// The wave walks its envs one at a time; the env's job sits in SGPRs (v_readlane),
+// so a load is `global_load_dwordx4 v, v_off, s[base]`.  Chunks of 64*U vectors are
+// software-pipelined: the loads of chunk c+1 are issued before the stores of chunk
+// c, so a wave keeps 2*U KiB of loads in flight and never waits for its own stores
+// (on CDNA4 vmcnt counts stores and loads together, in order).
+template <int VEC, bool NT, int U>
+__device__ inline void phase_b_rows(const Params& p, int wave_first, int n_env, int lane,
+                                    const ObsJob& job, uint64_t fv_magic) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  const uint32_t V = (uint32_t)(p.W * p.Fobs);
+  const uint32_t VPE = V / VEC;
+  const uint32_t FV = (uint32_t)p.Fobs / VEC;
+  constexpr uint32_t CH = 64u * U;  // vectors per chunk
+
+  // chunk cursor: (env in wave, first vector of the chunk); wave-uniform
+  int el = 0;
+  uint32_t j0 = 0;
+  auto load_chunk = [&](int e_l, uint32_t j_0, vec_t (&v)[U], JobView& jb) {
+    jb = broadcast_job(job, e_l);
+    if (!(jb.flags & 1)) return;  // uniform
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t j = j_0 + (uint32_t)u * 64u + (uint32_t)lane;
+      if (j < VPE) v[u] = *(const vec_t*)(jb.src + (int64_t)j * VEC);
+    }
+  };
+  auto store_chunk = [&](int e_l, uint32_t j_0, vec_t (&v)[U], const JobView& jb) {
+    if (!(jb.flags & 1)) return;
+    float* const dst = p.obs + (int64_t)(wave_first + e_l) * V;
+    const float* ring_e = p.ring + (int64_t)(wave_first + e_l) * p.depth * p.nd;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t j = j_0 + (uint32_t)u * 64u + (uint32_t)lane;
+      if (j < VPE) {
+        const uint32_t w = fastdiv40(j, fv_magic);
+        const int col = (int)(j - w * FV) * VEC;
+        patch_dynamic<VEC>(p, v[u], ring_e, (int)w, col, jb);
+        store_out<NT>((vec_t*)(dst + (int64_t)j * VEC), v[u]);
+      }
+    }
+  };
+
+  vec_t va[U], vb[U];
+  JobView ja, jbn;
+  load_chunk(el, j0, va, ja);
+  while (el < n_env) {
+    int el_n = el;
+    uint32_t j0_n = j0 + CH;
+    if (j0_n >= VPE) { j0_n = 0; el_n = el + 1; }
+    if (el_n < n_env) load_chunk(el_n, j0_n, vb, jbn);
+    store_chunk(el, j0, va, ja);
+#pragma unroll
+    for (int u = 0; u < U; ++u) va[u] = vb[u];
+    ja = jbn;
+    el = el_n;
+    j0 = j0_n;
   }
 }
 
@@ -363,11 +444,15 @@ __device__ inline void zero_fresh_stores(const Params& p, int wave_first, int n_
   }
 }
 
-template <int MODE, int VEC, bool NT>
+// ROWS_U == 0: flat gather; ROWS_U = 1..4: rows gather with chunks of 64*ROWS_U vectors
+template <int MODE, int VEC, bool NT, int ROWS_U>
 __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t vpe_magic,
                                                   const uint64_t fv_magic) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // the terminal counter has two slots used alternately, so no memset launch is
+  // needed between steps: this launch clears the slot the NEXT launch will use
+  if (MODE == MODE_STEP && blockIdx.x == 0 && threadIdx.x == 0) p.term_count_next[0] = 0;
   const int wave_first = wave * p.epw;
   if (wave_first >= p.N) return;  // whole wave exits together
   const int n_env = min(p.epw, p.N - wave_first);
@@ -375,7 +460,8 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
   ObsJob job;
   phase_a<MODE>(p, e, lane < n_env, lane, job);
   if (p.persist) zero_fresh_stores(p, wave_first, n_env, lane, job);
-  phase_b_flat<VEC, NT, 4>(p, wave_first, n_env, lane, job, vpe_magic, fv_magic);
+  if (ROWS_U == 0) phase_b_flat<VEC, NT, 4>(p, wave_first, n_env, lane, job, vpe_magic, fv_magic);
+  else phase_b_rows<VEC, NT, (ROWS_U ? ROWS_U : 1)>(p, wave_first, n_env, lane, job, fv_magic);
 }
 
 // ---------------------------------------------------------------------------
@@ -383,27 +469,39 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
 
 static uint64_t magic40(uint32_t d) { return ((1ull << 40) + d - 1) / d; }
 
+// rows_u: 0 = flat gather, 1..4 = rows gather (only with 16-byte vectors)
 template <int MODE>
-static hipError_t launch_mode(const Params& p, int vec, bool nt, int blocks, int threads,
-                              hipStream_t stream) {
+static hipError_t launch_mode(const Params& p, int vec, bool nt, int rows_u, int blocks,
+                              int threads, hipStream_t stream) {
   const uint32_t V = (uint32_t)(p.W * p.Fobs);
   const uint64_t vm = magic40(V / vec), fm = magic40((uint32_t)p.Fobs / vec);
-#define GTE_LAUNCH(VEC, NT) \
-  hipLaunchKernelGGL((gte_kernel<MODE, VEC, NT>), dim3(blocks), dim3(threads), 0, stream, p, vm, fm)
-  if (vec == 4) { if (nt) GTE_LAUNCH(4, true); else GTE_LAUNCH(4, false); }
-  else          { if (nt) GTE_LAUNCH(1, true); else GTE_LAUNCH(1, false); }
+#define GTE_LAUNCH(VEC, NT, RU) \
+  hipLaunchKernelGGL((gte_kernel<MODE, VEC, NT, RU>), dim3(blocks), dim3(threads), 0, stream, p, vm, fm)
+#define GTE_LAUNCH_NT(VEC, RU) do { if (nt) GTE_LAUNCH(VEC, true, RU); else GTE_LAUNCH(VEC, false, RU); } while (0)
+  if (vec == 4) {
+    switch (rows_u) {
+      case 1: GTE_LAUNCH_NT(4, 1); break;
+      case 2: GTE_LAUNCH_NT(4, 2); break;
+      case 3: GTE_LAUNCH_NT(4, 3); break;
+      case 4: GTE_LAUNCH_NT(4, 4); break;
+      default: GTE_LAUNCH_NT(4, 0); break;
+    }
+  } else {
+    GTE_LAUNCH_NT(1, 0);
+  }
+#undef GTE_LAUNCH_NT
 #undef GTE_LAUNCH
   return hipGetLastError();
 }
 
-hipError_t launch_step(const Params& p, int vec, bool nt, int blocks, int threads,
+hipError_t launch_step(const Params& p, int vec, bool nt, int rows_u, int blocks, int threads,
                        hipStream_t stream) {
-  return launch_mode<MODE_STEP>(p, vec, nt, blocks, threads, stream);
+  return launch_mode<MODE_STEP>(p, vec, nt, rows_u, blocks, threads, stream);
 }
 
-hipError_t launch_reset(const Params& p, int vec, bool nt, int blocks, int threads,
+hipError_t launch_reset(const Params& p, int vec, bool nt, int rows_u, int blocks, int threads,
                         hipStream_t stream) {
-  return launch_mode<MODE_RESET>(p, vec, nt, blocks, threads, stream);
+  return launch_mode<MODE_RESET>(p, vec, nt, rows_u, blocks, threads, stream);
 }
 
 }  // namespace gte

@@ -108,7 +108,11 @@ typedef struct gte_config {
                                are keyed by global env id, so a sharded run
                                equals the unsharded one)                       */
   int32_t envs_per_wave;    /* 0 = choose automatically                        */
-  int32_t nontemporal_obs;  /* 1: stream observation stores past L2 (default 0)*/
+  int32_t nontemporal_obs;  /* 1: non-temporal observation stores (keeps the feature
+                               table in L2/Infinity Cache; measured +4..25 %)     */
+  int32_t gather_path;      /* observation gather: 0 auto (= flat), 1 flat, 2 rows
+                               (see csrc/gte_kernels.hip phase B)               */
+  int32_t reserved0;
 } gte_config;
 
 /* Device pointers of the per-step return values of TradingEnv.step
@@ -119,9 +123,14 @@ typedef struct gte_outputs {
   double*  reward64;   /* f64 [N]  (the value the f32 one was rounded from)    */
   uint8_t* terminated; /* u8  [N]  `done` (:246)                               */
   uint8_t* truncated;  /* u8  [N]  (:248-251)                                  */
-  int32_t* term_count; /* i32 [1]  number of envs that ended this step         */
+  int32_t* term_count; /* i32 [2]  two slots used alternately (so that no clearing
+                          launch sits between steps); term_count[term_slot] is
+                          the number of envs whose flags are raised after the
+                          last step                                            */
   int32_t* term_ids;   /* i32 [N]  their ids, compacted (order unspecified)    */
   int64_t  obs_elems_per_env; /* W*F_obs                                       */
+  int32_t  term_slot;  /* which slot the last launch used (set by gte_get_outputs) */
+  int32_t  reserved0;
 } gte_outputs;
 
 /* Device pointers of the per-env state (struct of arrays), i.e. the fields of

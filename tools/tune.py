@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""In-process A/B of step-kernel variants on one GPU (interleaved rounds, HIP events).
+
+    python tools/tune.py [--workload c3] [--steps 300] [--rounds 5] variant ...
+variant = gather:epw:nt, e.g. rows:16:0 flat:16:0 rows:8:1
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c3")
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--envs", type=int, default=0)
+    ap.add_argument("--duration", type=int, default=0)
+    ap.add_argument("variants", nargs="+")
+    a = ap.parse_args()
+    import torch
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    wl = dict(bench.WORKLOADS[a.workload])
+    if a.duration:
+        wl["max_episode_duration"] = a.duration if a.duration > 0 else "max"
+    N = a.envs or wl["envs"]
+    feat, close = bench.synthetic_dataset(0, wl["T"], wl["n_static"])
+    dev = torch.device("cuda", 0)
+    acts = torch.randint(0, 3, (64, N), dtype=torch.int32, device=dev)
+    envs = {}
+    for v in a.variants:
+        g, epw, nt = v.split(":")
+        envs[v] = BatchedTradingEnv((feat, close), num_envs=N, seed=1, output="torch",
+                                    gather_path=g, envs_per_wave=int(epw),
+                                    nontemporal_obs=bool(int(nt)), **bench.env_kwargs(wl))
+        envs[v].reset()
+        for i in range(50):
+            envs[v].step(acts[i % 64])
+    torch.cuda.synchronize()
+    res = {v: [] for v in envs}
+    for r in range(a.rounds):
+        for v, e in envs.items():
+            e.timer_start()
+            for i in range(a.steps):
+                e.step(acts[i % 64])
+            res[v].append(e.timer_stop() * 1e3 / a.steps)
+    W = wl["windows"] or 1
+    b_alg = bench.algorithmic_bytes(W, wl["n_static"] + 2, wl["n_static"], 2)
+    for v, t in res.items():
+        med, mn = float(np.median(t)), float(np.min(t))
+        print(f"{v:14s} {envs[v].launch_info()} us/step median {med:7.2f} min {mn:7.2f}  "
+              f"-> {N / med:8.1f} M env-steps/s, {b_alg * N / med / 1e3:7.1f} GB/s alg "
+              f"({b_alg * N / med / 1e3 / 80:.1f}% of 8 TB/s)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
