@@ -152,23 +152,19 @@ def main():
     env.reset()
 
     # per-step return of a sharded run: one RCCL all-gather of the packed
-    # (reward f32 | terminated u8 | truncated u8) records, 6 bytes per env
-    packed = gathered = obs_all = None
+    # (reward f32 | terminated u8 | truncated u8) records, 6 bytes per env, which the
+    # kernel writes directly in that layout (env.packed_returns)
+    returns = None
     if world > 1:
-        packed = torch.empty(6 * N, dtype=torch.uint8, device=dev)
-        gathered = torch.empty(world * 6 * N, dtype=torch.uint8, device=dev)
-        if args.gather_obs:
-            obs_all = torch.empty((world * N, W, F_obs), dtype=torch.float32, device=dev)
+        from gym_trading_env_amd.distributed import ReturnGather
+        returns = ReturnGather(N, dev, obs_shape=env.obs_shape if args.gather_obs else None)
 
     def one_step(i):
         obs, reward, term, trunc, _ = env.step(actions[i % n_rows])
-        if world > 1:
-            packed[:4 * N].copy_(reward.view(torch.uint8))
-            packed[4 * N:5 * N].copy_(term.view(torch.uint8))
-            packed[5 * N:].copy_(trunc.view(torch.uint8))
-            dist.all_gather_into_tensor(gathered, packed)
-            if obs_all is not None:
-                dist.all_gather_into_tensor(obs_all, obs.view(N, W, F_obs))
+        if returns is not None:
+            returns.gather(env.packed_returns)
+            if args.gather_obs:
+                returns.gather_obs(obs)
 
     for i in range(args.warmup):
         one_step(i)

@@ -188,12 +188,15 @@ class BatchedTradingEnv:
         dev = torch.device("cuda", self.cfg.device)
         N = self.num_envs
         with torch.cuda.device(dev):
+            # reward | terminated | truncated live in ONE buffer (distributed.packed_layout)
+            # so that a sharded run all-gathers it without a packing kernel
+            self.packed_returns = torch.zeros(6 * N, dtype=torch.uint8, device=dev)
             self._t = {
                 "obs": torch.zeros((N,) + self.obs_shape, dtype=torch.float32, device=dev),
-                "reward": torch.zeros(N, dtype=torch.float32, device=dev),
+                "reward": self.packed_returns[:4 * N].view(torch.float32),
                 "reward64": torch.zeros(N, dtype=torch.float64, device=dev),
-                "terminated": torch.zeros(N, dtype=torch.bool, device=dev),
-                "truncated": torch.zeros(N, dtype=torch.bool, device=dev),
+                "terminated": self.packed_returns[4 * N:5 * N].view(torch.bool),
+                "truncated": self.packed_returns[5 * N:].view(torch.bool),
                 "term_count": torch.zeros(2, dtype=torch.int32, device=dev),  # two slots
                 "term_ids": torch.zeros(N, dtype=torch.int32, device=dev),
             }
