@@ -27,3 +27,21 @@ def __getattr__(name):
         mod = importlib.import_module(f"{__name__}.{_LAZY[name]}")
         return getattr(mod, name)
     raise AttributeError(name)
+
+
+def register_gymnasium_ids():
+    """Register 'TradingEnv' and 'MultiDatasetTradingEnv' like the reference's
+    __init__.py:3-14 (same ids and flags).  No-op when gymnasium is not installed."""
+    try:
+        from gymnasium.envs.registration import register, registry
+    except Exception:
+        return False
+    from . import envs
+    for env_id, cls in (("TradingEnv", envs.TradingEnv),
+                        ("MultiDatasetTradingEnv", envs.MultiDatasetTradingEnv)):
+        if env_id not in registry:
+            register(id=env_id, entry_point=cls, disable_env_checker=True, order_enforce=False)
+    return True
+
+
+register_gymnasium_ids()

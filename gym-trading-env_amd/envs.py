@@ -1,0 +1,280 @@
+"""Drop-in `TradingEnv` / `MultiDatasetTradingEnv`: the reference's single-environment
+API (src/gym_trading_env/environments.py:26-400) on top of the HIP hot path.
+
+One environment is a batch of one: every step is one libgte launch (the arithmetic
+never runs on the host) and the results are copied back to build the same return
+values as the reference: `(obs ndarray, reward, done, truncated, info dict)`, a
+`History` log, episode metrics, `save_for_render`.  Episode draws use NumPy's GLOBAL
+legacy RNG with the reference's calls in the reference's order
+(`np.random.choice(positions)` :167, `np.random.randint(low, high)` :174,
+`np.random.randint(n)` :385) and are injected into the kernel, so under
+`np.random.seed(k)` the drop-in replays the reference's episodes exactly.
+
+This N=1 form is interpreter- and PCIe-bound like the reference; throughput comes from
+`BatchedTradingEnv`.  Differences, all documented in DESIGN.md: dynamic features and
+device rewards are limited to the built-ins (custom `reward_function` callables run on
+the host over the History); limit orders are not implemented yet.
+"""
+from __future__ import annotations
+
+import datetime
+import glob
+import os
+from pathlib import Path
+
+import numpy as np
+
+from . import _abi, spaces, staging
+from .batched import BatchedTradingEnv
+from .config import _REWARD_BY_NAME, resolve_dynamic_features
+from .history import History
+
+try:  # soft dependency
+    import gymnasium as _gym
+    _EnvBase = _gym.Env
+except Exception:  # gymnasium absent: same reset(seed=) contract, nothing else needed
+    class _EnvBase:
+        metadata = {}
+
+        def reset(self, seed=None, options=None):
+            if seed is not None:
+                self.np_random = np.random.default_rng(seed)
+
+
+def basic_reward_function(history: History):
+    """ln(pv_t / pv_{t-1}) — recognised by name and computed on the device."""
+    return np.log(history["portfolio_valuation", -1] / history["portfolio_valuation", -2])
+
+
+def dynamic_feature_last_position_taken(history):
+    return history["position", -1]
+
+
+def dynamic_feature_real_position(history):
+    return history["real_position", -1]
+
+
+class TradingEnv(_EnvBase):
+    """Single-asset trading environment; same constructor as the reference (:79-93)."""
+
+    metadata = {"render_modes": ["logs"]}
+
+    def __init__(self, df, positions=[0, 1],
+                 dynamic_feature_functions=[dynamic_feature_last_position_taken,
+                                            dynamic_feature_real_position],
+                 reward_function=basic_reward_function, windows=None, trading_fees=0,
+                 borrow_interest_rate=0, portfolio_initial_value=1000,
+                 initial_position="random", max_episode_duration="max", verbose=1,
+                 name="Stock", render_mode="logs", device=0):
+        self.max_episode_duration = max_episode_duration
+        self.name = name
+        self.verbose = verbose
+        self.positions = positions
+        self.dynamic_feature_functions = dynamic_feature_functions
+        self.reward_function = reward_function
+        self.windows = windows
+        self.trading_fees = trading_fees
+        self.borrow_interest_rate = borrow_interest_rate
+        self.portfolio_initial_value = float(portfolio_initial_value)
+        self.initial_position = initial_position
+        assert self.initial_position in self.positions or self.initial_position == "random", (
+            "The 'initial_position' parameter must be 'random' or a position mentionned in the "
+            "'position' (default is [0, 1]) parameter.")
+        assert render_mode is None or render_mode in self.metadata["render_modes"]
+        self.render_mode = render_mode
+        self._device = device
+        resolve_dynamic_features(dynamic_feature_functions)  # refuses custom callables
+        rname = getattr(reward_function, "__name__", reward_function)
+        # a custom reward callable is evaluated on the host over the History (:265-267)
+        self._host_reward = not (isinstance(reward_function, tuple) or rname in _REWARD_BY_NAME)
+        self._batch = None
+        self._set_df(df)
+        self.action_space = spaces.Discrete(len(positions))
+        shape = [self._nb_features] if windows is None else [windows, self._nb_features]
+        self.observation_space = spaces.Box(-np.inf, np.inf, shape=shape)
+        self.log_metrics = []
+
+    # -- data staging (:128-143) ---------------------------------------------------------
+    def _set_df(self, df):
+        self.df = df.copy()
+        n_dyn = len(self.dynamic_feature_functions)
+        self._staged = staging.stage_dataframe(self.df, n_dyn=n_dyn, name=self.name)
+        self._features_columns = self._staged.feature_columns
+        self._info_columns = self._staged.info_columns
+        self._nb_static_features = self._staged.n_static
+        self._nb_features = self._staged.n_obs
+        self._info_array = self._staged.info_array
+        self._price_array = self._staged.close
+        if self._batch is not None:
+            self._batch.close()
+        # a fresh batch == a fresh `_obs_array` (dynamic columns zero); dyn_persist keeps
+        # this env's in-place dynamic-feature writes across episodes like :153-154
+        self._batch = BatchedTradingEnv(
+            self._staged, num_envs=1, positions=self.positions,
+            dynamic_feature_functions=self.dynamic_feature_functions,
+            reward_function="basic_reward_function" if self._host_reward else self.reward_function,
+            windows=self.windows, trading_fees=self.trading_fees,
+            borrow_interest_rate=self.borrow_interest_rate,
+            portfolio_initial_value=self.portfolio_initial_value,
+            initial_position=self.initial_position,
+            max_episode_duration=self.max_episode_duration, verbose=0, name=self.name,
+            autoreset=None, dyn_persist=True, device=self._device, output="numpy")
+
+    # -- helpers -------------------------------------------------------------------------
+    def _sync_state(self):
+        b = self._batch
+        self._idx = int(b.state("idx")[0])
+        self._step = int(b.state("step")[0])
+        self._position = self.positions[int(b.state("position_index")[0])]
+        self._portfolio_state = {k: float(b.state(k)[0]) for k in
+                                 ("asset", "fiat", "interest_asset", "interest_fiat")}
+        self._portfolio_value = float(b.state("portfolio_valuation")[0])
+        self._real_position = float(b.state("real_position")[0])
+
+    def _distribution(self):  # Portfolio.get_portfolio_distribution, portfolio.py:49-57
+        s = self._portfolio_state
+        return {"asset": max(0, s["asset"]), "fiat": max(0, s["fiat"]),
+                "borrowed_asset": max(0, -s["asset"]), "borrowed_fiat": max(0, -s["fiat"]),
+                "interest_asset": s["interest_asset"], "interest_fiat": s["interest_fiat"]}
+
+    def _get_price(self, delta=0):
+        return self._price_array[self._idx + delta]
+
+    def _get_ticker(self, delta=0):
+        return self.df.iloc[self._idx + delta]
+
+    def _obs(self):
+        return self._batch.read_output("obs")[0]
+
+    # -- reset (:163-199) ----------------------------------------------------------------
+    def reset(self, seed=None, options=None, **kwargs):
+        super().reset(seed=seed, options=options, **kwargs)
+        position = (np.random.choice(self.positions) if self.initial_position == "random"
+                    else self.initial_position)
+        idx = 0 if self.windows is None else self.windows - 1
+        if self.max_episode_duration != "max":
+            idx = np.random.randint(low=idx, high=len(self.df) - self.max_episode_duration - idx)
+        self._limit_orders = {}
+        self._batch.reset(inject_idx=[int(idx)],
+                          inject_position_index=[self.positions.index(position)])
+        self._sync_state()
+        self.historical_info = History(max_size=len(self.df))
+        self.historical_info.set(
+            idx=self._idx, step=self._step, date=self.df.index.values[self._idx],
+            position_index=self.positions.index(self._position), position=self._position,
+            real_position=self._position,
+            data=dict(zip(self._info_columns, self._info_array[self._idx])),
+            portfolio_valuation=self.portfolio_initial_value,
+            portfolio_distribution=self._distribution(), reward=0)
+        return self._obs(), self.historical_info[0]
+
+    def render(self):
+        pass
+
+    def add_limit_order(self, position, limit, persistent=False):
+        raise NotImplementedError(
+            "limit orders (environments.py:217-231) are not implemented on the device path yet")
+
+    # -- step (:233-272) -----------------------------------------------------------------
+    def step(self, position_index=None):
+        if position_index is not None:
+            self.positions[position_index]  # IndexError / TypeError like :234
+        if self._idx + 1 >= len(self._price_array):
+            raise IndexError(f"index {self._idx + 1} is out of bounds for axis 0 with size "
+                             f"{len(self._price_array)}")  # :239 past the last row
+        self._batch.step([-1 if position_index is None else int(position_index)])
+        self._sync_state()
+        done = bool(self._batch.read_output("terminated")[0])
+        truncated = bool(self._batch.read_output("truncated")[0])
+        self.historical_info.add(
+            idx=self._idx, step=self._step, date=self.df.index.values[self._idx],
+            position_index=position_index, position=self._position,
+            real_position=self._real_position,
+            data=dict(zip(self._info_columns, self._info_array[self._idx])),
+            portfolio_valuation=self._portfolio_value,
+            portfolio_distribution=self._distribution(), reward=0)
+        if not done:
+            reward = (self.reward_function(self.historical_info) if self._host_reward
+                      else np.float64(self._batch.read_output("reward64")[0]))
+            self.historical_info["reward", -1] = reward
+        if done or truncated:
+            self.calculate_metrics()
+            self.log()
+        return (self._obs(), self.historical_info["reward", -1], done, truncated,
+                self.historical_info[-1])
+
+    # -- metrics / logs (:274-294) ---------------------------------------------------------
+    def add_metric(self, name, function):
+        self.log_metrics.append({"name": name, "function": function})
+
+    def calculate_metrics(self):
+        h = self.historical_info
+        self.results_metrics = {
+            "Market Return": f"{100 * (h['data_close', -1] / h['data_close', 0] - 1):5.2f}%",
+            "Portfolio Return":
+                f"{100 * (h['portfolio_valuation', -1] / h['portfolio_valuation', 0] - 1):5.2f}%",
+        }
+        for metric in self.log_metrics:
+            self.results_metrics[metric["name"]] = metric["function"](h)
+
+    def get_metrics(self):
+        return self.results_metrics
+
+    def log(self):
+        if self.verbose > 0:
+            print("".join(f"{k} : {v}   |   " for k, v in self.results_metrics.items()))
+
+    def save_for_render(self, dir="render_logs"):
+        """Pickle `df` joined with the episode History (:296-307), for the renderer."""
+        import pandas as pd
+        assert all(c in self.df for c in ("open", "high", "low", "close")), (
+            "Your DataFrame needs to contain columns : open, high, low, close to render !")
+        cols = [c for c in self.historical_info.columns
+                if c not in {f"date_{col}" for col in self._info_columns}]
+        history_df = pd.DataFrame(self.historical_info[cols], columns=cols)
+        history_df.set_index("date", inplace=True)
+        history_df.sort_index(inplace=True)
+        render_df = self.df.join(history_df, how="inner")
+        os.makedirs(dir, exist_ok=True)
+        stamp = datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S")
+        render_df.to_pickle(f"{dir}/{self.name}_{stamp}.pkl")
+
+    def close(self):
+        if self._batch is not None:
+            self._batch.close()
+            self._batch = None
+
+
+class MultiDatasetTradingEnv(TradingEnv):
+    """A TradingEnv that moves to another dataset every
+    `episodes_between_dataset_switch` episodes (:365-400): uniform choice among the
+    least-used datasets, `preprocess` applied to each loaded frame."""
+
+    def __init__(self, dataset_dir, *args, preprocess=lambda df: df,
+                 episodes_between_dataset_switch=1, **kwargs):
+        self.dataset_dir = dataset_dir
+        self.preprocess = preprocess
+        self.episodes_between_dataset_switch = episodes_between_dataset_switch
+        self.dataset_pathes = glob.glob(self.dataset_dir)
+        if len(self.dataset_pathes) == 0:
+            raise FileNotFoundError(f"No dataset found with the path : {self.dataset_dir}")
+        self.dataset_nb_uses = np.zeros(shape=(len(self.dataset_pathes),))
+        super().__init__(self.next_dataset(), *args, **kwargs)
+
+    def next_dataset(self):
+        import pandas as pd
+        self._episodes_on_this_dataset = 0
+        candidates = np.where(self.dataset_nb_uses == self.dataset_nb_uses.min())[0]
+        dataset_idx = candidates[np.random.randint(candidates.size)]
+        self.dataset_nb_uses[dataset_idx] += 1
+        path = self.dataset_pathes[dataset_idx]
+        self.name = Path(path).name
+        return self.preprocess(pd.read_pickle(path))  # the user's own dataset files
+
+    def reset(self, seed=None, options=None, **kwargs):
+        self._episodes_on_this_dataset += 1
+        if self._episodes_on_this_dataset % self.episodes_between_dataset_switch == 0:
+            self._set_df(self.next_dataset())
+        if self.verbose > 1:
+            print(f"Selected dataset {self.name} ...")
+        return super().reset(seed=seed, options=options, **kwargs)

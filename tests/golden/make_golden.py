@@ -24,6 +24,8 @@ Trace format (one .npz per scenario, E reference env objects x K calls):
   portfolio_valuation, reward f64 [K, E]
   done, truncated u8 [K, E]
   obs     f32 [K, E, (W,) F_obs]                     observation returned
+  seed_base, fresh_env_each_episode: np.random.seed(seed_base + 7919*e + episode) was
+  called before every reset of env e; whether a new env object was built per episode
 Call k of env e follows Gymnasium's NEXT_STEP convention: the call after a
 terminal step is the reset (reward 0, flags false), so a batched env with
 next-step auto-reset replays the whole trace with one reset() + K-1 step()s.
@@ -172,6 +174,9 @@ def run_trace(make_env, positions, n_envs, n_calls, action_rng, p_none=0.1,
                 obs_rec = np.zeros((n_calls, n_envs) + obs.shape, np.float32)
             obs_rec[k, e] = obs
     rec["obs"] = obs_rec
+    # what a replay through the single-env API needs to reproduce the global-RNG draws
+    rec["seed_base"] = np.array(seed_base)
+    rec["fresh_env_each_episode"] = np.array(int(fresh_env_each_episode))
     return rec
 
 
@@ -184,6 +189,7 @@ def save(name, cfg, datasets, rec, note):
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     ends = int((rec["done"] | rec["truncated"]).sum())
+    assert rec["op"].ndim == 2
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, calls={rec['op'].shape}, "
           f"resets={int((rec['op'] == 0).sum())}, ends={ends}, done={int(rec['done'].sum())}")
 
