@@ -355,6 +355,11 @@ def main():
                                               **ref_kwargs(cfg))
             rec = run_trace(mk, cfg["positions"], n_envs=4, n_calls=330, action_rng=rng,
                             ds_names=[len(c) for _, c in sets])
+            # glob order is filesystem order (environments.py:375) and decides which file
+            # `np.random.randint(n)` (:385) selects: record it for single-env replays
+            import glob as _glob
+            rec["glob_order"] = np.array([names.index(os.path.basename(q))
+                                          for q in _glob.glob(os.path.join(tmp, "*.pkl"))], np.int32)
             save(f"multidataset_{tag}", cfg, sets, rec,
                  f"MultiDatasetTradingEnv, 5 datasets of different lengths, switch every "
                  f"{switch} episode(s); with switch > 1 a dataset's _obs_array "

@@ -142,18 +142,19 @@ def test_tradingenv_metrics_history_and_errors(tmp_path):
 
 
 @pytest.mark.parametrize("name,switch", [("multidataset_k1", 1), ("multidataset_k3", 3)])
-def test_multidataset_dropin_replays_reference(tmp_path, name, switch):
-    from gym_trading_env_amd import MultiDatasetTradingEnv
+def test_multidataset_dropin_replays_reference(tmp_path, monkeypatch, name, switch):
+    from gym_trading_env_amd import MultiDatasetTradingEnv, envs
     g = replay.load(name)
     g["close_ds"] = [c for _, c in g["datasets"]]
     for d, (feat, close) in enumerate(g["datasets"]):
         make_df(feat, close).to_pickle(tmp_path / f"sym{d}.pkl")
-    import glob
-    here = [len(pd.read_pickle(p)) for p in glob.glob(str(tmp_path / "*.pkl"))]
-    there = [len(c) for c in g["close_ds"]]
-    if here != there:
-        pytest.skip("glob order of this filesystem differs from the generator's; the draw "
-                    "`np.random.randint(n)` then selects other files (environments.py:375,385)")
+    # glob order is filesystem order (environments.py:375) and decides which file the draw
+    # np.random.randint(n) (:385) selects: present the files in the generator's order
+    order = [str(tmp_path / f"sym{d}.pkl") for d in g["glob_order"]]
+    real_glob = envs.glob.glob
+    monkeypatch.setattr(envs.glob, "glob",
+                        lambda pat: list(order) if pat.endswith("*.pkl") and "nothing" not in pat
+                        else real_glob(pat))
     kw = _kwargs(g)
     K, E = g["op"].shape
 

@@ -1,0 +1,77 @@
+"""BASELINE.json's full sizes on the GPU: a few steps against the OpenMP oracle on the
+same seeds (device Philox resets, no injection) and size-independent invariants over a
+longer run."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import _compare_with_oracle, _synthetic
+
+pytestmark = pytest.mark.gpu
+
+C3 = dict(windows=20, positions=[-1, 0, 1], trading_fees=1e-4, borrow_interest_rate=3e-6,
+          autoreset="next_step")
+
+
+def test_config3_full_size_vs_oracle(oracle_mod):
+    """65 536 envs x obs (20, 32), T = 100 000; short episodes so that resets happen."""
+    ds = [_synthetic(1234, 100_000, 30, sigma=1e-3)]
+    n = _compare_with_oracle(oracle_mod, ds, n_envs=65_536, steps=24, seed=11, check_every=8,
+                             max_episode_duration=9, **C3)
+    assert n > 0
+
+
+def test_config2_full_size_vs_oracle(oracle_mod):
+    """4 096 envs, 16-feature obs, no window, T = 100 000."""
+    ds = [_synthetic(1234, 100_000, 14, sigma=1e-3)]
+    _compare_with_oracle(oracle_mod, ds, n_envs=4_096, steps=60, seed=12, check_every=10,
+                         positions=[-1, 0, 1], trading_fees=1e-4, borrow_interest_rate=3e-6,
+                         max_episode_duration=25, autoreset="next_step")
+
+
+def test_config5_shape_many_datasets_vs_oracle(oracle_mod):
+    """1 024 resident datasets (config 5's count; T shortened to keep host memory small),
+    32 768 envs = one GPU's share of 262 144, per-env dataset indirection."""
+    ds = [_synthetic(2000 + d, 1200 + (d % 7) * 10, 30, sigma=2e-3) for d in range(1024)]
+    _compare_with_oracle(oracle_mod, ds, n_envs=32_768, steps=40, seed=13, check_every=10,
+                         max_episode_duration=12, **C3)
+
+
+def test_config3_invariants_long_run():
+    """600 steps at full size: properties that hold whatever the size."""
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    import torch
+    feat, close = _synthetic(1234, 100_000, 30, sigma=1e-3)
+    N = 65_536
+    env = BatchedTradingEnv((feat, close), num_envs=N, max_episode_duration=500, seed=3,
+                            output="torch", **C3)
+    obs, _ = env.reset()
+    dev = obs.device
+    table = torch.from_numpy(feat).to(dev)
+    acts = torch.randint(-1, 3, (64, N), dtype=torch.int32, device=dev)
+    ended_total = 0
+    for k in range(600):
+        obs, reward, term, trunc, info = env.step(acts[k % 64])
+        ended_total += int((term | trunc).sum())
+        if k % 100 == 99 or k < 3:
+            idx = torch.from_numpy(env.state("idx")).to(dev).long()
+            # static columns of the newest window row == the table row at idx (all envs)
+            assert torch.equal(obs[:, -1, :30], table[idx])
+            # ... and of the oldest window row == table row idx-19
+            assert torch.equal(obs[:, 0, :30], table[idx - 19])
+            # dynamic column 0 of the newest row == the position taken
+            pos = torch.tensor([-1.0, 0.0, 1.0], device=dev)[
+                torch.from_numpy(env.state("position_index")).to(dev).long()]
+            assert torch.equal(obs[:, -1, 30], pos)
+            st = {n: env.state(n) for n in ("idx", "step", "start_idx", "needs_reset", "episode")}
+            np.testing.assert_array_equal(st["idx"] - st["start_idx"], st["step"])
+            flags = (term | trunc).cpu().numpy()
+            np.testing.assert_array_equal(st["needs_reset"].astype(bool), flags)
+            np.testing.assert_array_equal(env.terminal_ids(), np.nonzero(flags)[0])
+            pv = env.state("portfolio_valuation")
+            assert np.isfinite(pv).all() and (pv > 0).all()
+            r = reward.cpu().numpy()
+            assert np.isfinite(r).all() and np.abs(r).max() < 0.1
+    # random starts in [19, 99481): every env hits the 500-step truncation once in 600 steps
+    assert ended_total >= N
+    assert (env.state("episode") >= 2).all()
+    env.close()
