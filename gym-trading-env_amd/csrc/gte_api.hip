@@ -440,7 +440,14 @@ int gte_get_state(gte_env* E, gte_state_view* out) {
 int gte_set_stream(gte_env* E, void* hip_stream) {
   if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
   HIPCHK(hipStreamSynchronize(E->stream));
-  E->stream = hip_stream ? (hipStream_t)hip_stream : E->own_stream;
+  E->stream = (hipStream_t)hip_stream;  // NULL = the null stream, used as such
+  return GTE_OK;
+}
+
+int gte_use_own_stream(gte_env* E) {
+  if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
+  HIPCHK(hipStreamSynchronize(E->stream));
+  E->stream = E->own_stream;
   return GTE_OK;
 }
 
@@ -495,7 +502,8 @@ int gte_get_launch_info(gte_env* E, int32_t* envs_per_wave, int32_t* threads_per
 void gte_destroy(gte_env* E) {
   if (!E) return;
   (void)hipSetDevice(E->cfg.device);
-  if (E->stream) (void)hipStreamSynchronize(E->stream);
+  (void)hipStreamSynchronize(E->stream);
+  if (E->own_stream) (void)hipStreamSynchronize(E->own_stream);
   for (void* ptr : E->allocs) (void)hipFree(ptr);
   for (auto& v : E->ds_allocs)
     for (void* ptr : v)

@@ -199,8 +199,11 @@ int gte_get_state(gte_env* env, gte_state_view* out);
  * then all-gathered over RCCL).  NULL members keep the library's buffer. */
 int gte_bind_outputs(gte_env* env, const gte_outputs* bufs);
 
-/* Run on this hipStream_t (NULL = the library's own stream). */
+/* Run on exactly this hipStream_t; NULL is HIP's null (default) stream, which is
+ * what PyTorch's default stream is.  A new env runs on a private non-blocking
+ * stream until this is called; gte_use_own_stream goes back to it. */
 int gte_set_stream(gte_env* env, void* hip_stream);
+int gte_use_own_stream(gte_env* env);
 int gte_synchronize(gte_env* env);
 
 /* HIP-event timing on the env's stream, for bench.py's roofline figure. */
