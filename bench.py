@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's)")
     ap.add_argument("--epw", type=int, default=0, help="envs per wavefront (0 = auto)")
     ap.add_argument("--nt", type=int, default=1, help="non-temporal observation stores (default 1)")
-    ap.add_argument("--gather", default="auto", choices=["auto", "flat", "rows"])
+    ap.add_argument("--variant", type=int, default=0, help="kernel_variant bits (A/B timing)")
     ap.add_argument("--gather-obs", action="store_true", help="also all-gather observations (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -143,7 +143,7 @@ def main():
     feat, close = synthetic_dataset(0, wl["T"], wl["n_static"])
     env = BatchedTradingEnv((feat, close), num_envs=N, seed=20240607, env_id_base=rank * N,
                             device=local_rank, output="torch", envs_per_wave=args.epw,
-                            nontemporal_obs=bool(args.nt), gather_path=args.gather,
+                            nontemporal_obs=bool(args.nt), kernel_variant=args.variant,
                             **env_kwargs(wl))
     gen = torch.Generator(device=dev)
     gen.manual_seed(99 + rank)

@@ -72,8 +72,8 @@ class GteConfig(C.Structure):
         ("env_id_base", C.c_int64),
         ("envs_per_wave", C.c_int32),
         ("nontemporal_obs", C.c_int32),
-        ("gather_path", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("kernel_variant", C.c_int32),
+        ("debug_flags", C.c_int32),
     ]
 
 

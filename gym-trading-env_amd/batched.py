@@ -113,7 +113,7 @@ class BatchedTradingEnv:
                  name="Stock", render_mode="logs", *, autoreset="next_step",
                  episodes_between_dataset_switch=1, dyn_persist=False, seed=0,
                  env_id_base=0, device=0, output="torch", envs_per_wave=0,
-                 nontemporal_obs=True, gather_path="auto", library_path=None):
+                 nontemporal_obs=True, kernel_variant=0, library_path=None, debug_flags=0):
         assert render_mode is None or render_mode in self.metadata["render_modes"]
         if output not in ("torch", "numpy"):
             raise ValueError("output must be 'torch' or 'numpy'")
@@ -146,7 +146,7 @@ class BatchedTradingEnv:
             autoreset=autoreset, episodes_between_dataset_switch=episodes_between_dataset_switch,
             dyn_persist=dyn_persist, seed=seed, env_id_base=env_id_base, device=device,
             envs_per_wave=envs_per_wave, nontemporal_obs=nontemporal_obs,
-            gather_path=gather_path)
+            kernel_variant=kernel_variant, debug_flags=debug_flags)
         _abi.check(self._lib, self._lib.gte_create(C.byref(self.cfg), C.byref(self._h)))
 
         self.n_obs = first.n_static + n_dyn
@@ -319,8 +319,9 @@ class BatchedTradingEnv:
         _abi.check(self._lib, self._lib.gte_get_launch_info(self._h, *[C.byref(x) for x in v]))
         d = dict(zip(("envs_per_wave", "threads_per_block", "n_blocks", "vector_bytes"),
                      (x.value for x in v)))
-        rows_u, d["vector_bytes"] = divmod(d["vector_bytes"], 1000)
-        d["gather"] = f"rows(chunk={64 * rows_u} vectors)" if rows_u else "flat"
+        flags, d["vector_bytes"] = divmod(d["vector_bytes"], 1000)
+        d["phase_a"] = "cooperative" if flags & 1 else "per-wave"
+        d["dyn_columns"] = ("global", "lds-raw-rings", "lds-resolved")[flags >> 1]
         return d
 
     def timer_start(self):

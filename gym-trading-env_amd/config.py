@@ -83,7 +83,8 @@ def make_config(*, n_envs: int, n_static: int, n_datasets: int = 1,
                 episodes_between_dataset_switch: int = 1,
                 dyn_persist: bool = False, seed: int = 0, env_id_base: int = 0,
                 device: int = 0, envs_per_wave: int = 0,
-                nontemporal_obs: bool = True, gather_path="auto") -> _abi.GteConfig:
+                nontemporal_obs: bool = True, kernel_variant: int = 0,
+                debug_flags: int = 0) -> _abi.GteConfig:
     positions = list(positions)
     if not 0 < len(positions) <= _abi.GTE_MAX_POSITIONS:
         raise ValueError(f"1..{_abi.GTE_MAX_POSITIONS} positions supported")
@@ -136,5 +137,6 @@ def make_config(*, n_envs: int, n_static: int, n_datasets: int = 1,
     cfg.env_id_base = int(env_id_base)
     cfg.envs_per_wave = int(envs_per_wave)
     cfg.nontemporal_obs = int(bool(nontemporal_obs))
-    cfg.gather_path = {"auto": 0, "flat": 1, "rows": 2}[gather_path]
+    cfg.kernel_variant = int(kernel_variant)
+    cfg.debug_flags = int(debug_flags)
     return cfg

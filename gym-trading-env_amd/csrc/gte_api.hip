@@ -17,10 +17,11 @@
 #include "gte_device.h"
 
 namespace gte {
-hipError_t launch_step(const Params& p, int vec, bool nt, int rows_u, int blocks, int threads,
-                       hipStream_t stream);
-hipError_t launch_reset(const Params& p, int vec, bool nt, int rows_u, int blocks, int threads,
-                        hipStream_t stream);
+hipError_t launch_step(const Params& p, int vec, bool nt, bool coop, int stage, int blocks,
+                       int threads, hipStream_t stream);
+hipError_t launch_reset(const Params& p, int vec, bool nt, bool coop, int stage, int blocks,
+                        int threads, hipStream_t stream);
+size_t lds_bytes(const Params& p, int stage);
 }  // namespace gte
 
 using gte::DatasetDesc;
@@ -65,7 +66,8 @@ struct gte_env {
   bool finalized = false;
   bool was_reset = false;
   int vec = 1, blocks = 0, threads = 256;
-  int rows_u = 0;          // 0: flat gather; 1..4: rows gather, chunk = 64*rows_u vectors
+  bool coop = false;       // wave 0 of a workgroup runs phase A for the whole workgroup
+  int stage = 0;           // dynamic columns: 0 global, 1 raw rings in LDS, 2 resolved in LDS
   int32_t* term_base = nullptr;  // the two-slot terminal counter in use (owned or bound)
   int term_slot = 0;       // slot the last launch added to
 };
@@ -246,16 +248,13 @@ int gte_create(const gte_config* cfg, gte_env** out) {
     while (epw < 64 && (int64_t)epw * vpe < 256) epw <<= 1;
   }
   while (epw > 1 && (int64_t)epw * vpe > (1 << 20)) epw >>= 1;  // keeps the index math in range
-  // observation gather: "rows" needs 16-byte vectors and windows of >= 64 vectors
-  const bool rows_ok = E->vec == 4 && vpe >= 64;
-  if (cfg->gather_path == 2 && !rows_ok) {
-    gte_destroy(E);
-    return fail(GTE_ERR_INVALID, "gather_path=rows needs F_obs %% 4 == 0 and window*F_obs >= 256");
-  }
-  // auto = flat: measured faster than rows at the headline shape (57 vs 63 us per step,
-  // profiles/r01_tune.log) because every lane of every wave instruction is used
-  E->rows_u = (cfg->gather_path == 2) ? (int)((vpe + 63) / 64 > 4 ? 4 : (vpe + 63) / 64) : 0;
+  // the LDS-staged dynamic columns must fit comfortably: shrink the workgroup's envs
+  while (epw > 1 && (int64_t)epw * 4 * p.W * (p.nd ? p.nd : 1) * 4 > 32 * 1024) epw >>= 1;
   p.epw = epw;
+  p.debug = cfg->debug_flags;
+  E->coop = (epw * 4 <= 64) && !(cfg->kernel_variant & 1);
+  E->stage = (p.nd > 0 && gte::lds_bytes(p, 1) <= 48 * 1024 && !(cfg->kernel_variant & 2))
+                 ? (p.persist ? 2 : 1) : 0;
   const int64_t waves = ((int64_t)p.N + epw - 1) / epw;
   E->threads = 256;
   E->blocks = (int)((waves + 3) / 4);
@@ -339,8 +338,8 @@ int gte_reset(gte_env* E, const uint8_t* mask, const int32_t* inj_idx,
   E->term_slot = 0;
   p.term_count = E->term_base;
   p.term_count_next = E->term_base + 1;
-  HIPCHK(gte::launch_reset(p, E->vec, E->cfg.nontemporal_obs != 0, E->rows_u, E->blocks, E->threads,
-                           E->stream));
+  HIPCHK(gte::launch_reset(p, E->vec, E->cfg.nontemporal_obs != 0, E->coop, E->stage, E->blocks,
+                           E->threads, E->stream));
   // host staging buffers may be reused by the caller right away: pageable copies above
   // are complete on return, but keep the contract simple and explicit
   HIPCHK(hipStreamSynchronize(E->stream));
@@ -391,8 +390,8 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
   E->term_slot ^= 1;
   p.term_count = E->term_base + E->term_slot;
   p.term_count_next = E->term_base + (E->term_slot ^ 1);
-  HIPCHK(gte::launch_step(p, E->vec, E->cfg.nontemporal_obs != 0, E->rows_u, E->blocks, E->threads,
-                          E->stream));
+  HIPCHK(gte::launch_step(p, E->vec, E->cfg.nontemporal_obs != 0, E->coop, E->stage, E->blocks,
+                          E->threads, E->stream));
   return GTE_OK;
 }
 
@@ -495,7 +494,7 @@ int gte_get_launch_info(gte_env* E, int32_t* envs_per_wave, int32_t* threads_per
   if (envs_per_wave) *envs_per_wave = E->p.epw;
   if (threads_per_block) *threads_per_block = E->threads;
   if (n_blocks) *n_blocks = E->blocks;
-  if (vector_bytes) *vector_bytes = E->vec * 4 + 1000 * E->rows_u;  // + 1000*rows_u
+  if (vector_bytes) *vector_bytes = E->vec * 4 + 1000 * ((E->coop ? 1 : 0) + 2 * E->stage);
   return GTE_OK;
 }
 

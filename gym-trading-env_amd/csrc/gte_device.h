@@ -58,6 +58,7 @@ struct Params {
   int32_t* q_head;
   // --- geometry
   int32_t epw;         // environments per wavefront
+  int32_t debug;       // gte_config.debug_flags (timing ablations)
 };
 
 // ---------------------------------------------------------------------------

@@ -2,8 +2,8 @@
 //
 // One launch advances every environment of the shard by one step
 // (TradingEnv.step, reference environments.py:233-272) or resets the masked
-// ones (TradingEnv.reset, :163-199).  Two phases inside one wavefront, no LDS
-// and no workgroup barrier:
+// ones (TradingEnv.reset, :163-199).  Two phases per 256-thread workgroup (4
+// wavefronts, 4*EPW environments), handed over through LDS with one barrier:
 //
 //   phase A  one lane per environment: the scalar fp64 state machine
 //            (_take_action/_trade -> Portfolio.trade_to_position ->
@@ -16,9 +16,9 @@
 //            :152-160): the window of env e is ONE contiguous block of
 //            W*F_obs floats of the row-major feature table, moved with
 //            16-byte loads/stores (1 KiB per wave instruction) and patched in
-//            flight with the dynamic columns, which come from a small per-env
-//            store in HBM (previous rows) and from phase A's registers
-//            (current row, broadcast with v_readlane / ds_bpermute).
+//            flight with the dynamic columns, which the wave first stages in
+//            LDS with one coalesced pass over its envs' small dynamic stores
+//            (previous rows) and phase A's results (current row).
 //
 // The kernel is HBM-bound (no contraction, so no MFMA): >= 97 % of its bytes
 // are the window gather + observation store.  See DESIGN.md for the roofline.
@@ -256,63 +256,108 @@ __device__ inline void store_out(T* dst, const T& v) {
   else *dst = v;
 }
 
-// job fields of the env a lane (flat path) or the whole wave (rows path) works on
-struct JobView {
-  const float* src;
-  int32_t slot0, n_zero, flags;
-  float cur[GTE_MAX_DYN];
+// LDS image of a workgroup: the jobs phase A hands to phase B (one per env of the
+// workgroup) and, when STAGE, the dynamic-column values of every window row.
+struct WgLds {
+  uint64_t* src;    // [EPB] first row of the window in the feature table
+  int32_t* flags;   // [EPB] bit0 copy the window, bit1 zero the env's dynamic store
+  int32_t* idx;     // [EPB]
+  int32_t* slot0;   // [EPB]
+  int32_t* n_zero;  // [EPB]
+  float* cur;       // [EPB][GTE_MAX_DYN]
+  float* staged;    // [EPB][W][nd]  (STAGE only)
 };
 
-// every lane reads the job of env `el` (per-lane el): ds_bpermute
-__device__ inline JobView shuffle_job(const ObsJob& job, int el) {
-  JobView b;
-  const uint64_t a = (uint64_t)job.src;
-  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)a, el);
-  const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(a >> 32), el);
-  b.src = (const float*)(((uint64_t)hi << 32) | lo);
-  b.slot0 = __shfl(job.slot0, el);
-  b.n_zero = __shfl(job.n_zero, el);
-  b.flags = __shfl(job.flags, el);
-#pragma unroll
-  for (int i = 0; i < GTE_MAX_DYN; ++i) b.cur[i] = __shfl(job.cur[i], el);
-  return b;
+__device__ inline WgLds carve_lds(unsigned char* base, int EPB) {
+  WgLds L;
+  L.src = (uint64_t*)base;                 base += 8 * EPB;
+  L.cur = (float*)base;                    base += 4 * GTE_MAX_DYN * EPB;
+  L.flags = (int32_t*)base;                base += 4 * EPB;
+  L.idx = (int32_t*)base;                  base += 4 * EPB;
+  L.slot0 = (int32_t*)base;                base += 4 * EPB;
+  L.n_zero = (int32_t*)base;               base += 4 * EPB;
+  L.staged = (float*)base;
+  return L;
 }
 
-// the whole wave reads the job of env `el` (wave-uniform el): v_readlane -> SGPRs
-__device__ inline JobView broadcast_job(const ObsJob& job, int el) {
-  JobView b;
-  const uint64_t a = (uint64_t)job.src;
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)a, el);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(a >> 32), el);
-  b.src = (const float*)(((uint64_t)hi << 32) | lo);
-  b.slot0 = __builtin_amdgcn_readlane(job.slot0, el);
-  b.n_zero = __builtin_amdgcn_readlane(job.n_zero, el);
-  b.flags = __builtin_amdgcn_readlane(job.flags, el);
+__device__ inline void publish_job(const WgLds& L, int slot, const ObsJob& job) {
+  L.src[slot] = (uint64_t)job.src;
+  L.flags[slot] = job.flags;
+  L.idx[slot] = job.idx;
+  L.slot0[slot] = job.slot0;
+  L.n_zero[slot] = job.n_zero;
 #pragma unroll
-  for (int i = 0; i < GTE_MAX_DYN; ++i)
-    b.cur[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(job.cur[i]), el));
-  return b;
+  for (int i = 0; i < GTE_MAX_DYN; ++i) L.cur[slot * GTE_MAX_DYN + i] = job.cur[i];
+}
+
+// value of dynamic feature i in window row w of the env in LDS slot `s`
+__device__ inline float dyn_value(const Params& p, const WgLds& L, int s, const float* ring_e,
+                                  int w, int i) {
+  if (w == p.W - 1) return L.cur[s * GTE_MAX_DYN + i];  // current row: from phase A
+  if (w < L.n_zero[s]) return 0.0f;                      // never written: reads as zero
+  int32_t slot = L.slot0[s] + w;
+  if (!p.persist && slot >= p.W) slot -= p.W;
+  return ring_e[(int64_t)slot * p.nd + i];
+}
+
+// The wave gathers, once and coalesced, the dynamic-column values of all window rows
+// of its envs into LDS (W*nd floats per env: 160 B at the headline shape), so that the
+// copy loop patches from LDS instead of issuing divergent global loads per vector.
+__device__ inline void stage_dynamic(const Params& p, const WgLds& L, int wg_first, int s_first,
+                                     int n_env, int lane, uint64_t wnd_magic) {
+  const uint32_t WND = (uint32_t)(p.W * p.nd);
+  const uint32_t total = (uint32_t)n_env * WND;
+  for (uint32_t k = (uint32_t)lane; k < total; k += 64u) {
+    const uint32_t el = fastdiv40(k, wnd_magic);
+    const uint32_t r = k - el * WND;
+    const uint32_t w = r / (uint32_t)p.nd;
+    const int i = (int)(r - w * (uint32_t)p.nd);
+    const int s = s_first + (int)el;
+    const float* ring_e = p.ring + (int64_t)(wg_first + s) * p.depth * p.nd;
+    L.staged[(uint32_t)s * WND + r] = dyn_value(p, L, s, ring_e, (int)w, i);
+  }
+}
+
+// STAGE_RAW: at kernel start every wave copies the W-deep rings of its envs — one
+// contiguous block of EPW*W*nd floats — into LDS (coalesced, and its latency hides
+// behind phase A); the slot rotation / zero rows / current row are resolved when a
+// vector is patched.  STAGE_LATE (dyn_persist: the rows sit at idx-dependent offsets
+// of a T-deep column): gathered after phase A, already resolved (stage_dynamic).
+enum { STAGE_NONE = 0, STAGE_RAW = 1, STAGE_LATE = 2 };
+
+__device__ inline void stage_raw_rings(const Params& p, const WgLds& L, int wg_first, int s_first,
+                                       int n_env, int lane) {
+  const uint32_t WND = (uint32_t)(p.W * p.nd);
+  const uint32_t total = (uint32_t)n_env * WND;
+  const float* src = p.ring + (int64_t)(wg_first + s_first) * WND;  // depth == W here
+  float* dst = L.staged + (uint32_t)s_first * WND;
+  for (uint32_t k = (uint32_t)lane; k < total; k += 64u) dst[k] = src[k];
+}
+
+__device__ inline float dyn_value_raw(const Params& p, const WgLds& L, int s, int w, int i) {
+  if (w == p.W - 1) return L.cur[s * GTE_MAX_DYN + i];
+  if (w < L.n_zero[s]) return 0.0f;
+  int32_t slot = L.slot0[s] + w;
+  if (slot >= p.W) slot -= p.W;
+  return L.staged[(s * p.W + slot) * p.nd + i];
 }
 
 // Overwrite the dynamic columns that vector `v` (columns col .. col+VEC-1 of window
-// row w) covers.  Every array index below is a compile-time constant after
-// unrolling: a run-time index into cur[] or v[] would put them in scratch memory
-// (one scratch store per observation store — measured as 2x WRITE_SIZE).
-template <int VEC, typename vec_t>
-__device__ inline void patch_dynamic(const Params& p, vec_t& v, const float* ring_e, int w,
-                                     int col, const JobView& jb) {
-  if (col + VEC <= p.Fs) return;  // all static columns
-  int32_t slot = jb.slot0 + w;
-  if (!p.persist && slot >= p.W) slot -= p.W;
-  const bool is_cur = (w == p.W - 1);          // current row: phase A's registers
-  const bool from_store = !is_cur && w >= jb.n_zero;  // else: never written -> 0
+// row w of the env in LDS slot s) covers.  Every index into v is a compile-time
+// constant after unrolling: a run-time index would put v in scratch memory (measured:
+// one scratch store per observation store, 2x WRITE_SIZE).
+template <int VEC, int STAGE, typename vec_t>
+__device__ inline void patch_dynamic(const Params& p, const WgLds& L, vec_t& v, int s,
+                                     const float* ring_e, int w, int col) {
+  if (col + VEC <= p.Fs || (p.debug & 2)) return;  // all static columns
 #pragma unroll
   for (int i = 0; i < GTE_MAX_DYN; ++i) {
     if (i < p.nd) {
       const int c = p.Fs + i - col;  // component of v that holds dynamic feature i
       if (c >= 0 && c < VEC) {
-        float x = is_cur ? jb.cur[i] : 0.0f;
-        if (from_store) x = ring_e[(int64_t)slot * p.nd + i];
+        const float x = STAGE == STAGE_LATE  ? L.staged[(s * p.W + w) * p.nd + i]
+                        : STAGE == STAGE_RAW ? dyn_value_raw(p, L, s, w, i)
+                                             : dyn_value(p, L, s, ring_e, w, i);
         if (VEC == 1) {
           v = x;
         } else {
@@ -324,24 +369,23 @@ __device__ inline void patch_dynamic(const Params& p, vec_t& v, const float* rin
   }
 }
 
-// "flat" gather — any shape.  The wave's n_env*VPE vectors form one index space,
-// lane l of iteration t handles vector t*64+l, so every wave instruction stores
-// 64*VEC*4 contiguous bytes whatever the window size (also when an env's window is
-// smaller than one wave instruction, e.g. windows=None).  The env differs per
-// lane, so the job fields travel through ds_bpermute.
-template <int VEC, bool NT, int U>
-__device__ inline void phase_b_flat(const Params& p, int wave_first, int n_env, int lane,
-                                    const ObsJob& job, uint64_t vpe_magic, uint64_t fv_magic) {
+// Window gather.  The wave's n_env*VPE vectors form one index space; lane l of
+// iteration t handles vector t*64+l, so every wave instruction loads/stores 64*VEC*4
+// contiguous, fully used bytes whatever the window size (also when an env's window is
+// smaller than one wave instruction, e.g. windows=None).  The env differs per lane:
+// its job is read from LDS.  U independent loads are in flight per lane.
+template <int VEC, bool NT, int STAGE, int U>
+__device__ inline void phase_b(const Params& p, const WgLds& L, int wg_first, int s_first,
+                               int n_env, int lane, uint64_t vpe_magic, uint64_t fv_magic) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
   const uint32_t V = (uint32_t)(p.W * p.Fobs);
   const uint32_t VPE = V / VEC;                // vectors per env
   const uint32_t FV = (uint32_t)p.Fobs / VEC;  // vectors per row
   const uint32_t total = (uint32_t)n_env * VPE;
-  float* const obs0 = p.obs + (int64_t)wave_first * V;
+  float* const obs0 = p.obs + (int64_t)(wg_first + s_first) * V;
 
   for (uint32_t k0 = 0; k0 < total; k0 += 64u * U) {
     vec_t v[U];
-    JobView jb[U];
     uint32_t jj[U], ee[U];
     bool ok[U];
 #pragma unroll
@@ -351,9 +395,9 @@ __device__ inline void phase_b_flat(const Params& p, int wave_first, int n_env, 
       const uint32_t kk = in ? k : 0u;
       ee[u] = fastdiv40(kk, vpe_magic);
       jj[u] = kk - ee[u] * VPE;
-      jb[u] = shuffle_job(job, (int)ee[u]);  // all lanes take part in the shuffles
-      ok[u] = in && (jb[u].flags & 1);
-      if (ok[u]) v[u] = *(const vec_t*)(jb[u].src + (int64_t)jj[u] * VEC);
+      const int s = s_first + (int)ee[u];
+      ok[u] = in && (L.flags[s] & 1);
+      if (ok[u]) v[u] = *(const vec_t*)((const float*)L.src[s] + (int64_t)jj[u] * VEC);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -361,82 +405,23 @@ __device__ inline void phase_b_flat(const Params& p, int wave_first, int n_env, 
       const uint32_t k = k0 + (uint32_t)u * 64u + (uint32_t)lane;
       const uint32_t w = fastdiv40(jj[u], fv_magic);
       const int col = (int)(jj[u] - w * FV) * VEC;
-      const float* ring_e = p.ring + (int64_t)(wave_first + (int)ee[u]) * p.depth * p.nd;
-      patch_dynamic<VEC>(p, v[u], ring_e, (int)w, col, jb[u]);
+      const int s = s_first + (int)ee[u];
+      const float* ring_e = p.ring + (int64_t)(wg_first + s) * p.depth * p.nd;
+      patch_dynamic<VEC, STAGE>(p, L, v[u], s, ring_e, (int)w, col);
       store_out<NT>((vec_t*)(obs0 + (int64_t)k * VEC), v[u]);
     }
   }
 }
 
-// "rows" gather — windows of at least one wave instruction (VPE >= 64 vectors).
-// The wave walks its envs one at a time; the env's job sits in SGPRs (v_readlane),
-// so a load is `global_load_dwordx4 v, v_off, s[base]`.  Chunks of 64*U vectors are
-// software-pipelined: the loads of chunk c+1 are issued before the stores of chunk
-// c, so a wave keeps 2*U KiB of loads in flight and never waits for its own stores
-// (on CDNA4 vmcnt counts stores and loads together, in order).
-template <int VEC, bool NT, int U>
-__device__ inline void phase_b_rows(const Params& p, int wave_first, int n_env, int lane,
-                                    const ObsJob& job, uint64_t fv_magic) {
-  typedef float vec_t __attribute__((ext_vector_type(VEC)));
-  const uint32_t V = (uint32_t)(p.W * p.Fobs);
-  const uint32_t VPE = V / VEC;
-  const uint32_t FV = (uint32_t)p.Fobs / VEC;
-  constexpr uint32_t CH = 64u * U;  // vectors per chunk
-
-  // chunk cursor: (env in wave, first vector of the chunk); wave-uniform
-  int el = 0;
-  uint32_t j0 = 0;
-  auto load_chunk = [&](int e_l, uint32_t j_0, vec_t (&v)[U], JobView& jb) {
-    jb = broadcast_job(job, e_l);
-    if (!(jb.flags & 1)) return;  // uniform
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t j = j_0 + (uint32_t)u * 64u + (uint32_t)lane;
-      if (j < VPE) v[u] = *(const vec_t*)(jb.src + (int64_t)j * VEC);
-    }
-  };
-  auto store_chunk = [&](int e_l, uint32_t j_0, vec_t (&v)[U], const JobView& jb) {
-    if (!(jb.flags & 1)) return;
-    float* const dst = p.obs + (int64_t)(wave_first + e_l) * V;
-    const float* ring_e = p.ring + (int64_t)(wave_first + e_l) * p.depth * p.nd;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t j = j_0 + (uint32_t)u * 64u + (uint32_t)lane;
-      if (j < VPE) {
-        const uint32_t w = fastdiv40(j, fv_magic);
-        const int col = (int)(j - w * FV) * VEC;
-        patch_dynamic<VEC>(p, v[u], ring_e, (int)w, col, jb);
-        store_out<NT>((vec_t*)(dst + (int64_t)j * VEC), v[u]);
-      }
-    }
-  };
-
-  vec_t va[U], vb[U];
-  JobView ja, jbn;
-  load_chunk(el, j0, va, ja);
-  while (el < n_env) {
-    int el_n = el;
-    uint32_t j0_n = j0 + CH;
-    if (j0_n >= VPE) { j0_n = 0; el_n = el + 1; }
-    if (el_n < n_env) load_chunk(el_n, j0_n, vb, jbn);
-    store_chunk(el, j0, va, ja);
-#pragma unroll
-    for (int u = 0; u < U; ++u) va[u] = vb[u];
-    ja = jbn;
-    el = el_n;
-    j0 = j0_n;
-  }
-}
-
 // zero the dynamic store of envs that switched dataset in persist mode (the
 // reference rebuilds _obs_array in _set_df), except the current row's slot
-__device__ inline void zero_fresh_stores(const Params& p, int wave_first, int n_env, int lane,
-                                         const ObsJob& job) {
+__device__ inline void zero_fresh_stores(const Params& p, const WgLds& L, int wg_first,
+                                         int s_first, int n_env, int lane) {
   for (int el = 0; el < n_env; ++el) {
-    const int flags = __builtin_amdgcn_readlane(job.flags, el);
-    if (!(flags & 2)) continue;
-    const int idx = __builtin_amdgcn_readlane(job.idx, el);
-    float* ring_e = p.ring + (int64_t)(wave_first + el) * p.depth * p.nd;
+    const int s = s_first + el;
+    if (!(L.flags[s] & 2)) continue;
+    const int idx = L.idx[s];
+    float* ring_e = p.ring + (int64_t)(wg_first + s) * p.depth * p.nd;
     const int64_t n = p.depth * p.nd;
     const int64_t keep_lo = (int64_t)idx * p.nd, keep_hi = keep_lo + p.nd;
     for (int64_t k = lane; k < n; k += 64)
@@ -444,24 +429,52 @@ __device__ inline void zero_fresh_stores(const Params& p, int wave_first, int n_
   }
 }
 
-// ROWS_U == 0: flat gather; ROWS_U = 1..4: rows gather with chunks of 64*ROWS_U vectors
-template <int MODE, int VEC, bool NT, int ROWS_U>
+// COOP: wave 0 of the workgroup runs phase A for all 4*EPW (<= 64) envs of the
+//       workgroup, one per lane at full lane utilisation (phase A is VALU-issue bound:
+//       ~3 000 cycles of fp64 per wave whatever the number of active lanes); otherwise
+//       every wave runs phase A for its own EPW envs.
+// STAGE: how the dynamic-column values reach the copy loop (STAGE_* above).
+template <int MODE, int VEC, bool NT, bool COOP, int STAGE>
 __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t vpe_magic,
-                                                  const uint64_t fv_magic) {
+                                                  const uint64_t fv_magic,
+                                                  const uint64_t wnd_magic) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gte_smem[];
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wib = threadIdx.x >> 6;  // wave in block
   // the terminal counter has two slots used alternately, so no memset launch is
   // needed between steps: this launch clears the slot the NEXT launch will use
   if (MODE == MODE_STEP && blockIdx.x == 0 && threadIdx.x == 0) p.term_count_next[0] = 0;
-  const int wave_first = wave * p.epw;
-  if (wave_first >= p.N) return;  // whole wave exits together
-  const int n_env = min(p.epw, p.N - wave_first);
-  const int e = wave_first + lane;
-  ObsJob job;
-  phase_a<MODE>(p, e, lane < n_env, lane, job);
-  if (p.persist) zero_fresh_stores(p, wave_first, n_env, lane, job);
-  if (ROWS_U == 0) phase_b_flat<VEC, NT, 4>(p, wave_first, n_env, lane, job, vpe_magic, fv_magic);
-  else phase_b_rows<VEC, NT, (ROWS_U ? ROWS_U : 1)>(p, wave_first, n_env, lane, job, fv_magic);
+  const int EPB = p.epw * 4;  // envs per workgroup
+  const int wg_first = blockIdx.x * EPB;
+  if (wg_first >= p.N) return;  // whole workgroup exits together (before any barrier)
+  const int n_wg = min(EPB, p.N - wg_first);
+  const WgLds L = carve_lds(gte_smem, EPB);
+  const int s_first = wib * p.epw;
+  const int n_env = min(p.epw, n_wg - s_first);
+  if (STAGE == STAGE_RAW && n_env > 0) stage_raw_rings(p, L, wg_first, s_first, n_env, lane);
+
+  // ---- phase A
+  if (!COOP || wib == 0) {  // wave-uniform
+    const int s = COOP ? lane : wib * p.epw + lane;  // LDS slot = env within the workgroup
+    const bool owns = COOP ? (lane < EPB) : (lane < p.epw);
+    ObsJob job;
+    phase_a<MODE>(p, wg_first + s, owns && s < n_wg, lane, job);
+    if (owns) publish_job(L, s, job);  // slots past the last env get flags = 0
+  }
+  __syncthreads();
+
+  // ---- phase B: each wave gathers the windows of its own EPW envs
+  if (n_env <= 0 || (p.debug & 1)) return;
+  if (p.persist) zero_fresh_stores(p, L, wg_first, s_first, n_env, lane);
+  if (STAGE == STAGE_LATE) {
+    stage_dynamic(p, L, wg_first, s_first, n_env, lane, wnd_magic);
+    // LDS operations of one wave execute in order; this only stops the compiler from
+    // moving the LDS reads of phase B above the staging writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  phase_b<VEC, NT, STAGE, 4>(p, L, wg_first, s_first, n_env, lane, vpe_magic, fv_magic);
 }
 
 // ---------------------------------------------------------------------------
@@ -469,39 +482,43 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
 
 static uint64_t magic40(uint32_t d) { return ((1ull << 40) + d - 1) / d; }
 
-// rows_u: 0 = flat gather, 1..4 = rows gather (only with 16-byte vectors)
+size_t lds_bytes(const Params& p, int stage) {
+  const size_t EPB = (size_t)p.epw * 4;
+  size_t b = EPB * (8 + 4 * GTE_MAX_DYN + 4 * 4);
+  if (stage) b += EPB * (size_t)p.W * (size_t)(p.nd ? p.nd : 1) * 4;
+  return b;
+}
+
 template <int MODE>
-static hipError_t launch_mode(const Params& p, int vec, bool nt, int rows_u, int blocks,
-                              int threads, hipStream_t stream) {
+static hipError_t launch_mode(const Params& p, int vec, bool nt, bool coop, int stage,
+                              int blocks, int threads, hipStream_t stream) {
   const uint32_t V = (uint32_t)(p.W * p.Fobs);
   const uint64_t vm = magic40(V / vec), fm = magic40((uint32_t)p.Fobs / vec);
-#define GTE_LAUNCH(VEC, NT, RU) \
-  hipLaunchKernelGGL((gte_kernel<MODE, VEC, NT, RU>), dim3(blocks), dim3(threads), 0, stream, p, vm, fm)
-#define GTE_LAUNCH_NT(VEC, RU) do { if (nt) GTE_LAUNCH(VEC, true, RU); else GTE_LAUNCH(VEC, false, RU); } while (0)
-  if (vec == 4) {
-    switch (rows_u) {
-      case 1: GTE_LAUNCH_NT(4, 1); break;
-      case 2: GTE_LAUNCH_NT(4, 2); break;
-      case 3: GTE_LAUNCH_NT(4, 3); break;
-      case 4: GTE_LAUNCH_NT(4, 4); break;
-      default: GTE_LAUNCH_NT(4, 0); break;
-    }
-  } else {
-    GTE_LAUNCH_NT(1, 0);
-  }
-#undef GTE_LAUNCH_NT
-#undef GTE_LAUNCH
+  const uint64_t wm = magic40((uint32_t)(p.W * (p.nd ? p.nd : 1)));
+  const size_t smem = lds_bytes(p, stage);
+#define GTE_L(VEC, NT, CO, ST) \
+  hipLaunchKernelGGL((gte_kernel<MODE, VEC, NT, CO, ST>), dim3(blocks), dim3(threads), smem, \
+                     stream, p, vm, fm, wm)
+#define GTE_L_ST(VEC, NT, CO) do { if (stage == STAGE_RAW) GTE_L(VEC, NT, CO, STAGE_RAW); \
+    else if (stage == STAGE_LATE) GTE_L(VEC, NT, CO, STAGE_LATE); else GTE_L(VEC, NT, CO, STAGE_NONE); } while (0)
+#define GTE_L_CO(VEC, NT) do { if (coop) GTE_L_ST(VEC, NT, true); else GTE_L_ST(VEC, NT, false); } while (0)
+#define GTE_L_NT(VEC) do { if (nt) GTE_L_CO(VEC, true); else GTE_L_CO(VEC, false); } while (0)
+  if (vec == 4) GTE_L_NT(4); else GTE_L_NT(1);
+#undef GTE_L_NT
+#undef GTE_L_CO
+#undef GTE_L_ST
+#undef GTE_L
   return hipGetLastError();
 }
 
-hipError_t launch_step(const Params& p, int vec, bool nt, int rows_u, int blocks, int threads,
-                       hipStream_t stream) {
-  return launch_mode<MODE_STEP>(p, vec, nt, rows_u, blocks, threads, stream);
+hipError_t launch_step(const Params& p, int vec, bool nt, bool coop, int stage, int blocks,
+                       int threads, hipStream_t stream) {
+  return launch_mode<MODE_STEP>(p, vec, nt, coop, stage, blocks, threads, stream);
 }
 
-hipError_t launch_reset(const Params& p, int vec, bool nt, int rows_u, int blocks, int threads,
-                        hipStream_t stream) {
-  return launch_mode<MODE_RESET>(p, vec, nt, rows_u, blocks, threads, stream);
+hipError_t launch_reset(const Params& p, int vec, bool nt, bool coop, int stage, int blocks,
+                        int threads, hipStream_t stream) {
+  return launch_mode<MODE_RESET>(p, vec, nt, coop, stage, blocks, threads, stream);
 }
 
 }  // namespace gte

@@ -110,9 +110,13 @@ typedef struct gte_config {
   int32_t envs_per_wave;    /* 0 = choose automatically                        */
   int32_t nontemporal_obs;  /* 1: non-temporal observation stores (keeps the feature
                                table in L2/Infinity Cache; measured +4..25 %)     */
-  int32_t gather_path;      /* observation gather: 0 auto (= flat), 1 flat, 2 rows
-                               (see csrc/gte_kernels.hip phase B)               */
-  int32_t reserved0;
+  int32_t kernel_variant;   /* 0 = auto.  Bits for A/B timing of the kernel structure:
+                               1 = every wave runs phase A for its own envs (no
+                               cooperative phase A), 2 = no LDS staging of the
+                               dynamic columns (see csrc/gte_kernels.hip)       */
+  int32_t debug_flags;      /* timing ablations only (results become wrong):
+                               1 = skip the observation gather, 2 = skip the
+                               dynamic-column patch                               */
 } gte_config;
 
 /* Device pointers of the per-step return values of TradingEnv.step

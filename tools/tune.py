@@ -2,7 +2,7 @@
 """In-process A/B of step-kernel variants on one GPU (interleaved rounds, HIP events).
 
     python tools/tune.py [--workload c3] [--steps 300] [--rounds 5] variant ...
-variant = gather:epw:nt, e.g. rows:16:0 flat:16:0 rows:8:1
+variant = kernel_variant:epw:nt[:debug_flags], e.g. 0:16:1 1:16:1 2:16:1 3:16:1 0:16:1:1
 """
 import argparse
 import os
@@ -34,10 +34,11 @@ def main():
     acts = torch.randint(0, 3, (64, N), dtype=torch.int32, device=dev)
     envs = {}
     for v in a.variants:
-        g, epw, nt = v.split(":")
+        kv, epw, nt, *dbg = v.split(":")
         envs[v] = BatchedTradingEnv((feat, close), num_envs=N, seed=1, output="torch",
-                                    gather_path=g, envs_per_wave=int(epw),
-                                    nontemporal_obs=bool(int(nt)), **bench.env_kwargs(wl))
+                                    kernel_variant=int(kv), envs_per_wave=int(epw),
+                                    nontemporal_obs=bool(int(nt)),
+                                    debug_flags=int(dbg[0]) if dbg else 0, **bench.env_kwargs(wl))
         envs[v].reset()
         for i in range(50):
             envs[v].step(acts[i % 64])
