@@ -134,6 +134,7 @@ SYMBOLS = {
     "gte_set_autoreset_injection": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p,
                                                C.c_void_p, C.c_void_p]),
     "gte_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "gte_add_limit_orders": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gte_get_outputs": (C.c_int, [C.c_void_p, _P(GteOutputs)]),
     "gte_get_state": (C.c_int, [C.c_void_p, _P(GteStateView)]),
     "gte_bind_outputs": (C.c_int, [C.c_void_p, _P(GteOutputs)]),

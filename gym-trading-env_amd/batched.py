@@ -22,8 +22,10 @@ _NP = {"int32": np.int32, "float64": np.float64}
 def _as_staged(ds, n_dyn, name="Stock"):
     if isinstance(ds, staging.StagedDataset):
         return ds
-    if isinstance(ds, tuple) and len(ds) == 2:
-        return staging.stage_arrays(ds[0], ds[1], n_dyn=n_dyn, name=name)
+    if isinstance(ds, tuple) and len(ds) in (2, 4):  # (features, close[, high, low])
+        return staging.stage_arrays(ds[0], ds[1], n_dyn=n_dyn, name=name,
+                                    high=ds[2] if len(ds) == 4 else None,
+                                    low=ds[3] if len(ds) == 4 else None)
     return staging.stage_dataframe(ds, n_dyn=n_dyn, name=name)  # a pandas DataFrame
 
 
@@ -91,7 +93,7 @@ class BatchedTradingEnv:
 
     :param df: one dataset or a list of datasets: pandas DataFrames (feature columns
         contain "feature", a "close" column), ``StagedDataset`` objects, or
-        ``(features[T, F_s], close[T])`` tuples.  Several datasets give the
+        ``(features[T, F_s], close[T][, high[T], low[T]])`` tuples.  Several datasets give the
         `MultiDatasetTradingEnv` behaviour (:365-400) with all of them resident.
     :param num_envs: N.
     :param autoreset: None/"disabled", "next_step" (Gymnasium >= 1.0) or "same_step".
@@ -128,7 +130,7 @@ class BatchedTradingEnv:
         from .config import resolve_dynamic_features
         n_dyn = len(resolve_dynamic_features(dynamic_feature_functions))
         raw = list(df) if isinstance(df, (list, tuple)) and not (
-            isinstance(df, tuple) and len(df) == 2 and hasattr(df[0], "shape")) else [df]
+            isinstance(df, tuple) and len(df) in (2, 4) and hasattr(df[0], "shape")) else [df]
         self.datasets = [_as_staged(d, n_dyn, name) for d in raw]
         first = self.datasets[0]
         for d in self.datasets:
@@ -281,6 +283,17 @@ class BatchedTradingEnv:
         b, bp = arr(position_index)
         c, cp = arr(dataset)
         _abi.check(self._lib, self._lib.gte_set_autoreset_injection(self._h, n, ap, bp, cp))
+
+    def add_limit_order(self, position_index, limit, persistent=False):
+        """`TradingEnv.add_limit_order` (environments.py:227-231) for a batch.
+
+        position_index: i32 [N] index into `positions` of each env's order target, -1 for
+        "no order for this env"; limit: f64 [N]; persistent: bool or bool [N]."""
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(position_index, np.int32), (self.num_envs,)))
+        b = np.ascontiguousarray(np.broadcast_to(np.asarray(limit, np.float64), (self.num_envs,)))
+        c = np.ascontiguousarray(np.broadcast_to(np.asarray(persistent, np.uint8), (self.num_envs,)))
+        _abi.check(self._lib, self._lib.gte_add_limit_orders(self._h, a.ctypes.data, b.ctypes.data,
+                                                             c.ctypes.data))
 
     def step(self, actions):
         """`TradingEnv.step` (environments.py:233-272) for every env in one launch.

@@ -22,6 +22,8 @@ hipError_t launch_step(const Params& p, int vec, bool nt, bool coop, int stage, 
 hipError_t launch_reset(const Params& p, int vec, bool nt, bool coop, int stage, int blocks,
                         int threads, hipStream_t stream);
 size_t lds_bytes(const Params& p, int stage);
+hipError_t launch_add_orders(const Params& p, const int32_t* pos_index, const double* limit,
+                             const uint8_t* persistent, hipStream_t stream);
 }  // namespace gte
 
 using gte::DatasetDesc;
@@ -63,6 +65,8 @@ struct gte_env {
   uint8_t* d_mask = nullptr;
   int32_t *d_inj_idx = nullptr, *d_inj_pos = nullptr, *d_inj_ds = nullptr;
   int32_t *d_q_idx = nullptr, *d_q_pos = nullptr, *d_q_ds = nullptr;
+  double* d_lo_limit_in = nullptr;  // staging for gte_add_limit_orders
+  uint8_t* d_lo_persist_in = nullptr;
   bool finalized = false;
   bool was_reset = false;
   int vec = 1, blocks = 0, threads = 256;
@@ -392,6 +396,38 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
   p.term_count_next = E->term_base + (E->term_slot ^ 1);
   HIPCHK(gte::launch_step(p, E->vec, E->cfg.nontemporal_obs != 0, E->coop, E->stage, E->blocks,
                           E->threads, E->stream));
+  return GTE_OK;
+}
+
+int gte_add_limit_orders(gte_env* E, const int32_t* pos_index, const double* limit,
+                         const uint8_t* persistent) {
+  if (!E || !pos_index || !limit) return fail(GTE_ERR_INVALID, "NULL argument");
+  if (!E->was_reset) return fail(GTE_ERR_STATE, "gte_add_limit_orders before gte_reset");
+  Params& p = E->p;
+  for (int d = 0; d < p.D; ++d)
+    if (!E->h_ds[d].high || !E->h_ds[d].low)
+      return fail(GTE_ERR_STATE, "limit orders need high/low columns in dataset %d", d);
+  const size_t N = (size_t)p.N;
+  for (size_t i = 0; i < N; ++i)
+    if (pos_index[i] >= p.P) return fail(GTE_ERR_INVALID, "pos_index[%zu] out of range", i);
+  HIPCHK(hipSetDevice(E->cfg.device));
+  if (!p.lo_n) {  // first use: allocate the order tables
+    TRY(dev_alloc(E, &p.lo_pos, N * p.P));
+    TRY(dev_alloc(E, &p.lo_limit, N * p.P));
+    TRY(dev_alloc(E, &p.lo_persist, N * p.P));
+    TRY(dev_alloc(E, &E->d_lo_limit_in, N));
+    TRY(dev_alloc(E, &E->d_lo_persist_in, N));
+    int32_t* lo_n = nullptr;
+    TRY(dev_alloc(E, &lo_n, N));
+    HIPCHK(hipDeviceSynchronize());
+    p.lo_n = lo_n;
+  }
+  TRY(stage(E, E->d_inj_pos, pos_index, 4 * N));
+  TRY(stage(E, E->d_lo_limit_in, limit, 8 * N));
+  if (persistent) TRY(stage(E, E->d_lo_persist_in, persistent, N));
+  HIPCHK(gte::launch_add_orders(p, E->d_inj_pos, E->d_lo_limit_in,
+                                persistent ? E->d_lo_persist_in : nullptr, E->stream));
+  HIPCHK(hipStreamSynchronize(E->stream));  // host arrays and staging buffers are free again
   return GTE_OK;
 }
 

@@ -40,6 +40,11 @@ struct Params {
   int32_t *idx, *step, *pos, *dsi, *start, *episode, *needs_reset, *eps_on_ds, *n_picks;
   double *asset, *fiat, *ia, *ifi, *pv, *realpos;
   float* ring;  // f32 [N, depth, nd]
+  // --- pending limit orders (null until the first gte_add_limit_orders)
+  int32_t* lo_n;        // i32 [N]
+  int32_t* lo_pos;      // i32 [N, P] target position index, insertion order
+  double* lo_limit;     // f64 [N, P]
+  uint8_t* lo_persist;  // u8  [N, P]
   // --- outputs
   float* obs;
   float* reward;

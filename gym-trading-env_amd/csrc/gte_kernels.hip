@@ -72,6 +72,7 @@ __device__ inline void do_reset(const Params& p, int e, int32_t inj_idx, int32_t
   reset_draws(p, e, s.episode, 0x52534554u, r);
   s.episode += 1;
   s.step = 0;  // :166
+  if (p.lo_n) p.lo_n[e] = 0;  // :168 self._limit_orders = {}
   int32_t pi = p.init_pos_index;  // :167
   if (pi < 0) pi = (inj_pos >= 0) ? inj_pos : bounded(r[0], p.P);
   s.pos = pi;
@@ -93,6 +94,58 @@ __device__ inline void do_reset(const Params& p, int e, int32_t inj_idx, int32_t
   s.pv = p.V0;          // :194
   s.realpos = position; // :192
   s.needs_reset = 0;
+}
+
+// TradingEnv._take_action_order_limit, environments.py:217-223: every pending order
+// whose target differs from the current position and whose limit lies inside
+// [low, high] of the NEW row trades at the limit price, in insertion order.  A filled
+// non-persistent order is removed (the reference deletes it while iterating its dict
+// and raises RuntimeError; the intended behaviour is implemented).
+__device__ inline void fill_limit_orders(const Params& p, int e, const DatasetDesc& d,
+                                         EnvRegs& s) {
+  const int n = p.lo_n[e];
+  if (n <= 0) return;
+  int32_t* lp = p.lo_pos + (int64_t)e * p.P;
+  double* ll = p.lo_limit + (int64_t)e * p.P;
+  uint8_t* lper = p.lo_persist + (int64_t)e * p.P;
+  const double hi = d.high[s.idx], lo = d.low[s.idx];
+  int k = 0;
+  for (int j = 0; j < n; ++j) {
+    const int32_t pi = lp[j];
+    const double limit = ll[j];
+    const uint8_t per = lper[j];
+    bool keep = true;
+    const double position = p.positions[pi];
+    if (position != p.positions[s.pos] && limit <= hi && limit >= lo) {
+      trade_to_position(s.q, position, limit, p.fees);  // _trade(position, price=limit)
+      s.pos = pi;
+      if (!per) keep = false;
+    }
+    if (keep) {
+      if (k != j) { lp[k] = pi; ll[k] = limit; lper[k] = per; }
+      ++k;
+    }
+  }
+  if (k != n) p.lo_n[e] = k;
+}
+
+// TradingEnv.add_limit_order, environments.py:227-231: `orders[position] = {...}` — an
+// existing key (a position VALUE) keeps its place in the iteration order, a new one
+// goes last.  One thread per env.
+__global__ void gte_add_orders_kernel(const Params p, const int32_t* pos_index,
+                                      const double* limit, const uint8_t* persistent) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.N) return;
+  const int32_t pi = pos_index[e];
+  if (pi < 0) return;
+  int32_t* lp = p.lo_pos + (int64_t)e * p.P;
+  const int n = p.lo_n[e];
+  int j = 0;
+  while (j < n && p.positions[lp[j]] != p.positions[pi]) ++j;
+  if (j == n) p.lo_n[e] = n + 1;  // n < P: at most one order per distinct position value
+  lp[j] = pi;
+  p.lo_limit[(int64_t)e * p.P + j] = limit[e];
+  p.lo_persist[(int64_t)e * p.P + j] = persistent ? persistent[e] : 0;
 }
 
 __device__ inline void pop_injection(const Params& p, int e, int32_t& qi, int32_t& qp,
@@ -201,6 +254,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
       }
       s.idx += 1;   // :235
       s.step += 1;  // :236
+      if (p.lo_n) fill_limit_orders(p, e, d, s);  // :238
       const double price = d.close[s.idx];  // :239
       s.q.ia = pymax0(-s.q.asset) * p.rate;   // update_interest, portfolio.py:44-46
       s.q.ifi = pymax0(-s.q.fiat) * p.rate;
@@ -508,6 +562,13 @@ static hipError_t launch_mode(const Params& p, int vec, bool nt, bool coop, int 
 #undef GTE_L_CO
 #undef GTE_L_ST
 #undef GTE_L
+  return hipGetLastError();
+}
+
+hipError_t launch_add_orders(const Params& p, const int32_t* pos_index, const double* limit,
+                             const uint8_t* persistent, hipStream_t stream) {
+  hipLaunchKernelGGL(gte_add_orders_kernel, dim3((p.N + 255) / 256), dim3(256), 0, stream, p,
+                     pos_index, limit, persistent);
   return hipGetLastError();
 }
 

@@ -13,7 +13,7 @@ legacy RNG with the reference's calls in the reference's order
 This N=1 form is interpreter- and PCIe-bound like the reference; throughput comes from
 `BatchedTradingEnv`.  Differences, all documented in DESIGN.md: dynamic features and
 device rewards are limited to the built-ins (custom `reward_function` callables run on
-the host over the History); limit orders are not implemented yet.
+the host over the History).
 """
 from __future__ import annotations
 
@@ -172,8 +172,14 @@ class TradingEnv(_EnvBase):
         pass
 
     def add_limit_order(self, position, limit, persistent=False):
-        raise NotImplementedError(
-            "limit orders (environments.py:217-231) are not implemented on the device path yet")
+        """Pending order (environments.py:227-231): when `low <= limit <= high` at a new
+        row and `position` differs from the current one, trade to it at `limit`.  The
+        order table lives on the device; `self._limit_orders` mirrors what was asked.
+        NB a filled non-persistent order is removed and the step goes on — the
+        reference deletes it while iterating its dict and raises RuntimeError (:223)."""
+        self._limit_orders[position] = {"limit": limit, "persistent": persistent}
+        self._batch.add_limit_order([self.positions.index(position)], [float(limit)],
+                                    bool(persistent))
 
     # -- step (:233-272) -----------------------------------------------------------------
     def step(self, position_index=None):

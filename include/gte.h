@@ -195,6 +195,16 @@ int gte_set_autoreset_injection(gte_env* env, int32_t n_episodes,
  * or a device pointer when actions_on_device != 0. */
 int gte_step(gte_env* env, const int32_t* actions, int32_t actions_on_device);
 
+/* TradingEnv.add_limit_order (environments.py:227-231) for every env with
+ * pos_index[i] >= 0 (HOST arrays of length N; persistent == NULL means all
+ * non-persistent).  A pending order fills in gte_step at the new row when
+ * low <= limit <= high and its target differs from the current position, trading
+ * at the limit price (:217-223); gte_reset clears an env's orders (:168).  Needs
+ * high/low in every uploaded dataset.  A filled non-persistent order is removed
+ * (the reference deletes it while iterating and raises RuntimeError). */
+int gte_add_limit_orders(gte_env* env, const int32_t* pos_index, const double* limit,
+                         const uint8_t* persistent);
+
 /* Where the results of the last gte_step / gte_reset live (device pointers). */
 int gte_get_outputs(gte_env* env, gte_outputs* out);
 int gte_get_state(gte_env* env, gte_state_view* out);

@@ -46,6 +46,13 @@ typedef struct gto_env {
   uint8_t *terminated, *truncated;
   int32_t term_count;
   int32_t* term_ids;
+  /* pending limit orders, insertion-ordered like the reference's dict (:227-231) */
+  double** high;
+  double** low;
+  int32_t* lo_n;      /* [N] */
+  int32_t* lo_pos;    /* [N, P] target position index */
+  double* lo_limit;   /* [N, P] */
+  uint8_t* lo_persist;/* [N, P] */
   /* queued draws for auto-resets */
   int32_t q_n;
   int32_t *q_idx, *q_pos, *q_ds, *q_head;
@@ -233,6 +240,7 @@ static void do_reset(gto_env* E, int32_t e, int32_t inj_idx, int32_t inj_pos,
   reset_draws(E, e, E->episode[e], 0x52534554u /* 'RSET' */, r);
   E->episode[e] += 1;
   E->step[e] = 0; /* :166 */
+  E->lo_n[e] = 0; /* :168 self._limit_orders = {} */
   int32_t p = c->initial_position_index; /* :167 */
   if (p < 0) p = (inj_pos >= 0) ? inj_pos : bounded(r[0], c->n_positions);
   E->pos[e] = p;
@@ -319,6 +327,31 @@ static int step_one(gto_env* E, int32_t e, int32_t action) {
   }
   E->idx[e] += 1;  /* :235 */
   E->step[e] += 1; /* :236 */
+  /* :238 _take_action_order_limit, :217-223: every pending order whose target differs
+   * from the current position and whose limit lies inside [low, high] of the NEW row
+   * trades at the limit price.  A filled non-persistent order is removed (the
+   * reference deletes it while iterating its dict and crashes with RuntimeError;
+   * the intended behaviour is restated here). */
+  if (E->lo_n[e] > 0 && E->high[d] && E->low[d]) {
+    const int P = c->n_positions;
+    int32_t* lp = E->lo_pos + (int64_t)e * P;
+    double* ll = E->lo_limit + (int64_t)e * P;
+    uint8_t* lper = E->lo_persist + (int64_t)e * P;
+    const double hi = E->high[d][E->idx[e]], lo = E->low[d][E->idx[e]];
+    int n = E->lo_n[e], k = 0;
+    for (int j = 0; j < n; ++j) {
+      int keep = 1;
+      double position = c->positions[lp[j]];
+      if (position != c->positions[E->pos[e]] && ll[j] <= hi && ll[j] >= lo) {
+        trade_to_position(&E->asset[e], &E->fiat[e], &E->ia[e], &E->ifi[e], position, ll[j],
+                          c->trading_fees);
+        E->pos[e] = lp[j];
+        if (!lper[j]) keep = 0;
+      }
+      if (keep) { lp[k] = lp[j]; ll[k] = ll[j]; lper[k] = lper[j]; ++k; }
+    }
+    E->lo_n[e] = k;
+  }
   double price = E->close[d][E->idx[e]]; /* :239 */
   /* Portfolio.update_interest, portfolio.py:44-46 (assignment, not +=) */
   E->ia[e] = pymax0(-E->asset[e]) * c->borrow_interest_rate;
@@ -370,13 +403,18 @@ gto_env* gto_create(const gte_config* cfg) {
   E->has_window = cfg->window > 0;
   E->W = E->has_window ? cfg->window : 1;
   E->feat = (float**)zalloc(sizeof(float*) * E->D);
+  E->high = (double**)zalloc(sizeof(double*) * E->D);
+  E->low = (double**)zalloc(sizeof(double*) * E->D);
   E->close = (double**)zalloc(sizeof(double*) * E->D);
   E->T = (int64_t*)zalloc(sizeof(int64_t) * E->D);
   size_t N = (size_t)E->N;
 #define I32(name) E->name = (int32_t*)zalloc(sizeof(int32_t) * N)
 #define F64(name) E->name = (double*)zalloc(sizeof(double) * N)
   I32(idx); I32(step); I32(pos); I32(ds); I32(start); I32(episode);
-  I32(needs_reset); I32(eps_on_ds); I32(n_picks); I32(term_ids); I32(q_head);
+  I32(needs_reset); I32(eps_on_ds); I32(n_picks); I32(term_ids); I32(q_head); I32(lo_n);
+  E->lo_pos = (int32_t*)zalloc(sizeof(int32_t) * N * cfg->n_positions);
+  E->lo_limit = (double*)zalloc(sizeof(double) * N * cfg->n_positions);
+  E->lo_persist = (uint8_t*)zalloc(N * cfg->n_positions);
   F64(asset); F64(fiat); F64(ia); F64(ifi); F64(pv); F64(realpos); F64(reward64);
 #undef I32
 #undef F64
@@ -412,6 +450,38 @@ static int finalize(gto_env* E) {
   E->depth = E->cfg.dyn_persist ? maxT : E->W;
   E->ring = (float*)zalloc(sizeof(float) * (size_t)E->N * E->depth *
                            (E->nd ? E->nd : 1));
+  return 0;
+}
+
+int gto_upload_high_low(gto_env* E, int32_t d, const double* high, const double* low) {
+  if (!E || d < 0 || d >= E->D || E->T[d] <= 0) return -1;
+  free(E->high[d]); free(E->low[d]);
+  E->high[d] = (double*)malloc(sizeof(double) * E->T[d]);
+  E->low[d] = (double*)malloc(sizeof(double) * E->T[d]);
+  memcpy(E->high[d], high, sizeof(double) * E->T[d]);
+  memcpy(E->low[d], low, sizeof(double) * E->T[d]);
+  return 0;
+}
+
+/* TradingEnv.add_limit_order, environments.py:227-231, one order per env with
+ * pos_index[e] >= 0: `self._limit_orders[position] = {...}` — an existing key keeps its
+ * place in the iteration order, a new key goes last. */
+int gto_add_limit_orders(gto_env* E, const int32_t* pos_index, const double* limit,
+                         const uint8_t* persistent) {
+  const int P = E->cfg.n_positions;
+  for (int32_t e = 0; e < E->N; ++e) {
+    int32_t pi = pos_index[e];
+    if (pi < 0) continue;
+    if (pi >= P) return -1;
+    int32_t* lp = E->lo_pos + (int64_t)e * P;
+    int n = E->lo_n[e], j = 0;
+    /* dict keys are position VALUES */
+    while (j < n && E->cfg.positions[lp[j]] != E->cfg.positions[pi]) ++j;
+    if (j == n) { if (n >= P) return -1; E->lo_n[e] = n + 1; }
+    lp[j] = pi;
+    E->lo_limit[(int64_t)e * P + j] = limit[e];
+    E->lo_persist[(int64_t)e * P + j] = persistent ? persistent[e] : 0;
+  }
   return 0;
 }
 
@@ -498,8 +568,9 @@ void gto_portfolio_trade(double* state4, double position, double price,
 
 void gto_destroy(gto_env* E) {
   if (!E) return;
-  for (int d = 0; d < E->D; ++d) { free(E->feat[d]); free(E->close[d]); }
-  free(E->feat); free(E->close); free(E->T);
+  for (int d = 0; d < E->D; ++d) { free(E->feat[d]); free(E->close[d]); free(E->high[d]); free(E->low[d]); }
+  free(E->feat); free(E->close); free(E->T); free(E->high); free(E->low);
+  free(E->lo_n); free(E->lo_pos); free(E->lo_limit); free(E->lo_persist);
   free(E->idx); free(E->step); free(E->pos); free(E->ds); free(E->start);
   free(E->episode); free(E->needs_reset); free(E->eps_on_ds); free(E->n_picks);
   free(E->asset); free(E->fiat); free(E->ia); free(E->ifi); free(E->pv);

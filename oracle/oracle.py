@@ -44,6 +44,8 @@ def lib() -> C.CDLL:
         l.gto_create.argtypes = [C.POINTER(GteConfig)]
         l.gto_upload_dataset.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]
         l.gto_reset.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        l.gto_upload_high_low.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        l.gto_add_limit_orders.argtypes = [C.c_void_p] * 4
         l.gto_set_autoreset_injection.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 3
         l.gto_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         l.gto_destroy.argtypes = [C.c_void_p]
@@ -70,7 +72,7 @@ class OracleEnv:
     """Batch of N reference-semantics environments on the CPU (fp64, scalar)."""
 
     def __init__(self, cfg: GteConfig, datasets):
-        """datasets: list of (feat f32 [T, F_obs], close f64 [T])."""
+        """datasets: list of (feat f32 [T, F_obs], close f64 [T][, high f64 [T], low f64 [T]])."""
         self._l = lib()
         self.cfg = cfg
         self.N = cfg.n_envs
@@ -80,13 +82,27 @@ class OracleEnv:
         if not self._h:
             raise RuntimeError("gto_create failed (ABI mismatch?)")
         assert len(datasets) == cfg.n_datasets
-        for d, (feat, close) in enumerate(datasets):
+        for d, ds in enumerate(datasets):
+            feat, close = ds[0], ds[1]
             feat = np.ascontiguousarray(feat, dtype=np.float32)
             close = np.ascontiguousarray(close, dtype=np.float64)
             assert feat.shape == (close.shape[0], self.F), (feat.shape, close.shape, self.F)
             rc = self._l.gto_upload_dataset(self._h, d, feat.ctypes.data, close.ctypes.data,
                                             close.shape[0])
             assert rc == 0
+            if len(ds) >= 4 and ds[2] is not None:
+                hi = np.ascontiguousarray(ds[2], dtype=np.float64)
+                lo = np.ascontiguousarray(ds[3], dtype=np.float64)
+                assert self._l.gto_upload_high_low(self._h, d, hi.ctypes.data, lo.ctypes.data) == 0
+
+    def add_limit_orders(self, pos_index, limit, persistent=None):
+        a = np.ascontiguousarray(pos_index, dtype=np.int32)
+        b = np.ascontiguousarray(limit, dtype=np.float64)
+        c = None if persistent is None else np.ascontiguousarray(persistent, dtype=np.uint8)
+        assert a.shape == b.shape == (self.N,)
+        rc = self._l.gto_add_limit_orders(self._h, a.ctypes.data, b.ctypes.data,
+                                          None if c is None else c.ctypes.data)
+        assert rc == 0
 
     def _view(self, name, dtype, shape):
         p = getattr(self._l, "gto_get_" + name)(self._h)

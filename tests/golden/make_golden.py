@@ -88,9 +88,10 @@ FIELDS_F64 = ("position", "real_position", "asset", "fiat", "interest_asset",
 FIELDS_I32 = ("idx", "step", "pos_index", "dataset")
 
 
-def make_df(feat, close):
+def make_df(feat, close, high=None, low=None):
     T = len(close)
-    df = pd.DataFrame({"open": close, "high": close * 1.001, "low": close * 0.999,
+    df = pd.DataFrame({"open": close, "high": close * 1.001 if high is None else high,
+                       "low": close * 0.999 if low is None else low,
                        "close": close, "volume": np.ones(T)},
                       index=pd.date_range("2020-01-01", periods=T, freq="h"))
     for j in range(feat.shape[1]):
@@ -127,7 +128,7 @@ def snapshot(env, rec, k, e, positions, ds_names):
 
 def run_trace(make_env, positions, n_envs, n_calls, action_rng, p_none=0.1,
               fresh_env_each_episode=False, autoreset=True, ds_names=None,
-              seed_base=1000, actions=None):
+              seed_base=1000, actions=None, p_order=0.0):
     """Drive n_envs reference env objects for n_calls calls each."""
     rec = {f: np.zeros((n_calls, n_envs), np.float64) for f in FIELDS_F64}
     rec.update({f: np.zeros((n_calls, n_envs), np.int32) for f in FIELDS_I32})
@@ -135,6 +136,9 @@ def run_trace(make_env, positions, n_envs, n_calls, action_rng, p_none=0.1,
     rec["action"] = np.zeros((n_calls, n_envs), np.int32)
     rec["done"] = np.zeros((n_calls, n_envs), np.uint8)
     rec["truncated"] = np.zeros((n_calls, n_envs), np.uint8)
+    if p_order > 0:  # env.add_limit_order(position, limit, persistent=True) BEFORE call k
+        rec["lo_pos"] = np.full((n_calls, n_envs), -1, np.int32)
+        rec["lo_limit"] = np.zeros((n_calls, n_envs), np.float64)
     obs_rec = None
     P = len(positions)
     for e in range(n_envs):
@@ -160,6 +164,14 @@ def run_trace(make_env, positions, n_envs, n_calls, action_rng, p_none=0.1,
                 else:
                     a = -1 if action_rng.random() < p_none else int(action_rng.integers(0, P))
                 rec["action"][k, e] = a
+                if p_order > 0 and action_rng.random() < p_order:
+                    pi = int(action_rng.integers(0, P))
+                    limit = float(env._get_price() * (1 + action_rng.normal(0, 0.01)))
+                    # non-persistent orders crash the reference when they fill
+                    # (RuntimeError: dictionary changed size during iteration, :223)
+                    env.add_limit_order(positions[pi], limit, persistent=True)
+                    rec["lo_pos"][k, e] = pi
+                    rec["lo_limit"][k, e] = limit
                 try:
                     obs, reward, done, trunc, info = env.step(None if a < 0 else a)
                 except IndexError:
@@ -182,9 +194,12 @@ def run_trace(make_env, positions, n_envs, n_calls, action_rng, p_none=0.1,
 
 def save(name, cfg, datasets, rec, note):
     out = {"cfg_json": np.array(json.dumps(cfg)), "note": np.array(note)}
-    for d, (feat, close) in enumerate(datasets):
-        out[f"feat_{d}"] = np.asarray(feat, np.float32)
-        out[f"close_{d}"] = np.asarray(close, np.float64)
+    for d, ds in enumerate(datasets):
+        out[f"feat_{d}"] = np.asarray(ds[0], np.float32)
+        out[f"close_{d}"] = np.asarray(ds[1], np.float64)
+        if len(ds) == 4:
+            out[f"high_{d}"] = np.asarray(ds[2], np.float64)
+            out[f"low_{d}"] = np.asarray(ds[3], np.float64)
     out.update(rec)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
@@ -333,6 +348,19 @@ def main():
     save("reward_clipped_nodyn", cfg, [(feat, close)], rec,
          "fork usage (luckymodel/envs/env.py:16-18): np.clip(log_return, -0.002, 0.005), "
          "no dynamic features, no window")
+
+    # -- persistent limit orders (environments.py:217-231) ---------------------------
+    feat, close = random_walk(41, 260, 3, sigma=1e-2)
+    r2 = np.random.default_rng(42)
+    high = close * (1 + np.abs(r2.normal(0, 8e-3, 260)))
+    low = close * (1 - np.abs(r2.normal(0, 8e-3, 260)))
+    dfl = make_df(feat, close, high, low)
+    cfg = base_cfg(positions=[-1, 0, 1], windows=3, trading_fees=1e-3, borrow_interest_rate=1e-4)
+    rec = run_trace(lambda e: TradingEnv(df=dfl, **ref_kwargs(cfg)), cfg["positions"],
+                    n_envs=6, n_calls=600, action_rng=rng, p_none=0.5, p_order=0.15)
+    save("limit_orders", cfg, [(feat, close, high, low)], rec,
+         "persistent limit orders added between steps; they fill at the limit price when "
+         "low <= limit <= high at the new row, several may fill in one step, reset clears them")
 
     # -- MultiDatasetTradingEnv over pickles written by THIS script ------------------
     with tempfile.TemporaryDirectory() as tmp:

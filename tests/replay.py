@@ -33,7 +33,10 @@ def load(name):
     d = 0
     sets = []
     while f"feat_{d}" in g:
-        sets.append((g.pop(f"feat_{d}"), g.pop(f"close_{d}")))
+        ds = (g.pop(f"feat_{d}"), g.pop(f"close_{d}"))
+        if f"high_{d}" in g:
+            ds += (g.pop(f"high_{d}"), g.pop(f"low_{d}"))
+        sets.append(ds)
         d += 1
     g["datasets"] = sets
     return g
@@ -55,10 +58,11 @@ def config_kwargs(g, tile: int = 1, **over):
 def staged(g, n_dyn):
     """(feat [T, F_obs] with zero dynamic columns, close) per dataset."""
     out = []
-    for feat, close in g["datasets"]:
+    for ds in g["datasets"]:
+        feat = ds[0]
         full = np.zeros((feat.shape[0], feat.shape[1] + n_dyn), np.float32)
         full[:, :feat.shape[1]] = feat
-        out.append((full, close))
+        out.append((full,) + tuple(ds[1:]))
     return out
 
 
@@ -90,6 +94,9 @@ def replay(adapter, g, tile: int = 1, rtol: float = 1e-12, obs_exact: bool = Tru
     worst = 0.0
     for k in range(K):
         if k > 0:
+            if "lo_pos" in g and (g["lo_pos"][k] >= 0).any():
+                adapter.add_limit_orders(t(g["lo_pos"][k]), t(g["lo_limit"][k]),
+                                         np.ones(E * tile, np.uint8))
             adapter.step(t(g["action"][k]))
         st = adapter.state()
         tag = f"call {k}"

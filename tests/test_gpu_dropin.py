@@ -12,9 +12,10 @@ import replay
 pytestmark = pytest.mark.gpu
 
 
-def make_df(feat, close):
+def make_df(feat, close, high=None, low=None):
     T = len(close)
-    df = pd.DataFrame({"open": close, "high": close * 1.001, "low": close * 0.999,
+    df = pd.DataFrame({"open": close, "high": close * 1.001 if high is None else high,
+                       "low": close * 0.999 if low is None else low,
                        "close": close, "volume": np.ones(T)},
                       index=pd.date_range("2020-01-01", periods=T, freq="h"))
     for j in range(feat.shape[1]):
@@ -77,6 +78,9 @@ def _replay_env(g, e, make_env, calls):
             assert info["reward"] == 0 and info["position_index"] == g["pos_index"][k, e]
         else:
             a = int(g["action"][k, e])
+            if "lo_pos" in g and g["lo_pos"][k, e] >= 0:
+                env.add_limit_order(env.positions[int(g["lo_pos"][k, e])],
+                                    float(g["lo_limit"][k, e]), persistent=True)
             obs, reward, done, trunc, info = env.step(None if a < 0 else a)
             assert info["position_index"] == (None if a < 0 else a)
         _check_call(g, k, e, env, obs, reward, done, trunc, info, P)
@@ -84,16 +88,16 @@ def _replay_env(g, e, make_env, calls):
 
 
 SINGLE = ["c1_btc_default", "c1_btc_example", "c2_nowindow", "c3_window20", "drawdown_done",
-          "no_autoreset", "persist_dynamic", "reward_scaled_onedyn", "reward_clipped_nodyn"]
+          "no_autoreset", "persist_dynamic", "reward_scaled_onedyn", "reward_clipped_nodyn",
+          "limit_orders"]
 
 
 @pytest.mark.parametrize("name", SINGLE)
 def test_tradingenv_dropin_replays_reference(name):
     from gym_trading_env_amd import TradingEnv
     g = replay.load(name)
-    g["close_ds"] = [c for _, c in g["datasets"]]
-    feat, close = g["datasets"][0]
-    df = make_df(feat, close)
+    g["close_ds"] = [ds[1] for ds in g["datasets"]]
+    df = make_df(*g["datasets"][0])
     kw = _kwargs(g)
     K, E = g["op"].shape
     calls = min(K, 260)

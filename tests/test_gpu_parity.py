@@ -30,6 +30,9 @@ class GpuAdapter:
     def step(self, actions):
         self.env.step(np.asarray(actions, np.int32))
 
+    def add_limit_orders(self, pos, limit, persistent):
+        self.env.add_limit_order(pos, limit, persistent)
+
     obs = lambda s: s.env.read_output("obs")
     reward64 = lambda s: s.env.read_output("reward64")
     terminated = lambda s: s.env.read_output("terminated")
@@ -79,7 +82,8 @@ def _synthetic(seed, T, n_static, sigma=5e-3, drift=0.0):
     return feat, close
 
 
-def _compare_with_oracle(oracle_mod, datasets, n_envs, steps, seed, check_every=1, **kw):
+def _compare_with_oracle(oracle_mod, datasets, n_envs, steps, seed, check_every=1, p_order=0.0,
+                         **kw):
     """Drive the HIP env and the oracle with the same config, the same device-RNG
     seed (no injection: Philox draws on both sides) and the same actions."""
     from gym_trading_env_amd.batched import BatchedTradingEnv
@@ -87,10 +91,11 @@ def _compare_with_oracle(oracle_mod, datasets, n_envs, steps, seed, check_every=
                             output="numpy", seed=seed, **kw)
     n_dyn = env.cfg.n_dyn
     staged = []
-    for f, c in datasets:
+    for ds in datasets:
+        f = ds[0]
         full = np.zeros((f.shape[0], f.shape[1] + n_dyn), np.float32)
         full[:, :f.shape[1]] = f
-        staged.append((full, c))
+        staged.append((full,) + tuple(ds[1:]))
     ora = oracle_mod.OracleEnv(env.cfg, staged)
     env.reset()
     ora.reset()
@@ -102,6 +107,14 @@ def _compare_with_oracle(oracle_mod, datasets, n_envs, steps, seed, check_every=
     for k in range(steps + 1):
         if k > 0:
             a = rng.integers(-1, P, n_envs).astype(np.int32)
+            if p_order > 0:  # limit orders, persistent and not, on a random subset of envs
+                pi = np.where(rng.random(n_envs) < p_order, rng.integers(0, P, n_envs), -1).astype(np.int32)
+                idx_now = ora.state()["idx"]
+                px = np.array([datasets[d][1][i] for d, i in zip(ora.state()["dataset_index"], idx_now)])
+                lim = px * (1 + rng.normal(0, 0.01, n_envs))
+                per = (rng.random(n_envs) < 0.5).astype(np.uint8)
+                env.add_limit_order(pi, lim, per)
+                ora.add_limit_orders(pi, lim, per)
             env.step(a)
             ora.step(a, threads=8)
         if k % check_every and k != steps:
@@ -186,4 +199,27 @@ def test_hip_masked_reset_and_disabled_autoreset(oracle_mod):
         np.testing.assert_array_equal(env.read_output("obs"), ora.obs)
         np.testing.assert_array_equal(env.state("idx"), ora.state()["idx"])
         np.testing.assert_array_equal(env.state("episode"), ora.state()["episode"])
+    env.close()
+
+
+def test_hip_vs_oracle_limit_orders(oracle_mod):
+    """Persistent and non-persistent limit orders on random envs, several datasets."""
+    ds = []
+    for d in range(3):
+        f, c = _synthetic(400 + d, 220 + 10 * d, 5, sigma=1e-2)
+        r = np.random.default_rng(500 + d)
+        ds.append((f, c, c * (1 + np.abs(r.normal(0, 8e-3, len(c)))), c * (1 - np.abs(r.normal(0, 8e-3, len(c))))))
+    _compare_with_oracle(oracle_mod, ds, n_envs=1500, steps=150, seed=21, windows=3, p_order=0.2,
+                         positions=[-1, -0.5, 0, 1, 2], trading_fees=1e-3, borrow_interest_rate=1e-4,
+                         max_episode_duration=60, autoreset="next_step")
+
+
+def test_limit_orders_need_high_low():
+    from gym_trading_env_amd import GteError
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    f, c = _synthetic(1, 100, 2)
+    env = BatchedTradingEnv((f, c), num_envs=8, output="numpy")
+    env.reset()
+    with pytest.raises(GteError, match="high/low"):
+        env.add_limit_order(np.zeros(8, np.int32), c[:8], True)
     env.close()

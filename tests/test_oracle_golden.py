@@ -22,6 +22,9 @@ class OracleAdapter:
     def step(self, actions):
         self.env.step(actions)
 
+    def add_limit_orders(self, pos, limit, persistent):
+        self.env.add_limit_orders(pos, limit, persistent)
+
     obs = lambda s: s.env.obs
     reward64 = lambda s: s.env.reward64
     terminated = lambda s: s.env.terminated
