@@ -35,9 +35,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 WORKLOADS = {
-    # name: (n_static, windows, T, max_episode_duration)
-    "c3": dict(n_static=30, windows=20, T=100_000, max_episode_duration=500, envs=65_536),
-    "c2": dict(n_static=14, windows=None, T=100_000, max_episode_duration=500, envs=4_096),
+    # BASELINE.json configs[2] (headline), [1] and the per-GPU share of [4]
+    "c3": dict(n_static=30, windows=20, T=100_000, max_episode_duration=500, envs=65_536,
+               n_datasets=1),
+    "c2": dict(n_static=14, windows=None, T=100_000, max_episode_duration=500, envs=4_096,
+               n_datasets=1),
+    # config 5: 1 024 symbols x 256 envs over 8 GPUs = 128 resident datasets and 32 768
+    # envs per GPU, per-env dataset indirection, switch at every episode
+    "c5": dict(n_static=30, windows=20, T=100_000, max_episode_duration=500, envs=32_768,
+               n_datasets=128),
 }
 
 
@@ -140,8 +146,10 @@ def main():
     n_dyn = 2
     W = wl["windows"] or 1
     F_obs = wl["n_static"] + n_dyn
-    feat, close = synthetic_dataset(0, wl["T"], wl["n_static"])
-    env = BatchedTradingEnv((feat, close), num_envs=N, seed=20240607, env_id_base=rank * N,
+    D = wl["n_datasets"]
+    data = [synthetic_dataset(rank * D + d, wl["T"], wl["n_static"]) for d in range(D)]
+    env = BatchedTradingEnv(data if D > 1 else data[0], num_envs=N, seed=20240607,
+                            env_id_base=rank * N,
                             device=local_rank, output="torch", envs_per_wave=args.epw,
                             nontemporal_obs=bool(args.nt), kernel_variant=args.variant,
                             **env_kwargs(wl))
@@ -207,7 +215,7 @@ def main():
             "ms_per_step": el * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 state / f32 obs", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {N} envs/GPU x obs ({W},{F_obs}) f32, "
-                                   f"T={wl['T']}, positions [-1,0,1], fees 1e-4, borrow 3e-6, "
+                                   f"{D} dataset(s)/GPU of T={wl['T']}, positions [-1,0,1], fees 1e-4, borrow 3e-6, "
                                    f"max_episode_duration {wl['max_episode_duration']}, next-step autoreset",
                        "envs_per_gpu": N, "global_envs": world * N,
                        "parallelism": f"env-shard x{world}" + (

@@ -248,8 +248,10 @@ int gte_create(const gte_config* cfg, gte_env** out) {
     epw = 64;
     // enough wavefronts to fill 256 CUs x 16 waves ...
     while (epw > 1 && ((int64_t)p.N + epw - 1) / epw < 4096) epw >>= 1;
-    // ... but at least 256 vectors of copy work per wavefront
-    while (epw < 64 && (int64_t)epw * vpe < 256) epw <<= 1;
+    // ... but at least one full wave instruction (64 vectors) of copy work per wavefront
+    // (small windows are latency-bound: 16 envs/wave with cooperative phase A measured
+    // 5.4 us vs 7.5 us at 64 envs/wave on config 2, profiles/r01_tune_c2.log)
+    while (epw < 64 && (int64_t)epw * vpe < 64) epw <<= 1;
   }
   while (epw > 1 && (int64_t)epw * vpe > (1 << 20)) epw >>= 1;  // keeps the index math in range
   // the LDS-staged dynamic columns must fit comfortably: shrink the workgroup's envs
