@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--epw", type=int, default=0, help="envs per wavefront (0 = auto)")
     ap.add_argument("--nt", type=int, default=1, help="non-temporal observation stores (default 1)")
     ap.add_argument("--variant", type=int, default=0, help="kernel_variant bits (A/B timing)")
+    ap.add_argument("--affinity", type=int, default=0,
+                    help="L2-affinity re-sort period in steps (0 = default 128, -1 = off)")
     ap.add_argument("--gather-obs", action="store_true", help="also all-gather observations (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -151,7 +153,7 @@ def main():
     env = BatchedTradingEnv(data if D > 1 else data[0], num_envs=N, seed=20240607,
                             env_id_base=rank * N,
                             device=local_rank, output="torch", envs_per_wave=args.epw,
-                            nontemporal_obs=bool(args.nt), kernel_variant=args.variant,
+                            nontemporal_obs=bool(args.nt), kernel_variant=args.variant, affinity_period=args.affinity,
                             **env_kwargs(wl))
     gen = torch.Generator(device=dev)
     gen.manual_seed(99 + rank)

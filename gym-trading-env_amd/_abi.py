@@ -74,6 +74,8 @@ class GteConfig(C.Structure):
         ("nontemporal_obs", C.c_int32),
         ("kernel_variant", C.c_int32),
         ("debug_flags", C.c_int32),
+        ("affinity_period", C.c_int32),
+        ("reserved1", C.c_int32),
     ]
 
 

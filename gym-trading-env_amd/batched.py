@@ -115,7 +115,8 @@ class BatchedTradingEnv:
                  name="Stock", render_mode="logs", *, autoreset="next_step",
                  episodes_between_dataset_switch=1, dyn_persist=False, seed=0,
                  env_id_base=0, device=0, output="torch", envs_per_wave=0,
-                 nontemporal_obs=True, kernel_variant=0, library_path=None, debug_flags=0):
+                 nontemporal_obs=True, kernel_variant=0, library_path=None, debug_flags=0,
+                 affinity_period=0):
         assert render_mode is None or render_mode in self.metadata["render_modes"]
         if output not in ("torch", "numpy"):
             raise ValueError("output must be 'torch' or 'numpy'")
@@ -148,7 +149,8 @@ class BatchedTradingEnv:
             autoreset=autoreset, episodes_between_dataset_switch=episodes_between_dataset_switch,
             dyn_persist=dyn_persist, seed=seed, env_id_base=env_id_base, device=device,
             envs_per_wave=envs_per_wave, nontemporal_obs=nontemporal_obs,
-            kernel_variant=kernel_variant, debug_flags=debug_flags)
+            kernel_variant=kernel_variant, debug_flags=debug_flags,
+            affinity_period=affinity_period)
         _abi.check(self._lib, self._lib.gte_create(C.byref(self.cfg), C.byref(self._h)))
 
         self.n_obs = first.n_static + n_dyn
@@ -163,7 +165,7 @@ class BatchedTradingEnv:
             self.upload_dataset(d, s)
 
         self._state = _abi.GteStateView()
-        _abi.check(self._lib, self._lib.gte_get_state(self._h, C.byref(self._state)))
+        self._epoch, self._state_epoch = 0, -1  # state snapshots are taken lazily
         self._torch = None
         self._t = {}
         if output == "torch":
@@ -221,6 +223,9 @@ class BatchedTradingEnv:
     def state(self, name: str) -> np.ndarray:
         """Host copy of one per-env state array (struct gte_state_view member)."""
         dt = _NP[_abi.STATE_DTYPES[name]]
+        if self._state_epoch != self._epoch:  # snapshot once per step/reset, not per field
+            _abi.check(self._lib, self._lib.gte_get_state(self._h, C.byref(self._state)))
+            self._state_epoch = self._epoch
         return self._to_host(getattr(self._state, name), dt, self.num_envs)
 
     def read_output(self, name: str) -> np.ndarray:
@@ -268,6 +273,7 @@ class BatchedTradingEnv:
         c, cp = arr(inject_dataset, np.int32)
         _abi.check(self._lib, self._lib.gte_reset(self._h, mp, ap, bp, cp))
         self._was_reset = True
+        self._epoch += 1
         return self._results()[0], LazyInfo(self)
 
     def set_autoreset_injection(self, idx=None, position_index=None, dataset=None):
@@ -294,6 +300,7 @@ class BatchedTradingEnv:
         c = np.ascontiguousarray(np.broadcast_to(np.asarray(persistent, np.uint8), (self.num_envs,)))
         _abi.check(self._lib, self._lib.gte_add_limit_orders(self._h, a.ctypes.data, b.ctypes.data,
                                                              c.ctypes.data))
+        self._epoch += 1
 
     def step(self, actions):
         """`TradingEnv.step` (environments.py:233-272) for every env in one launch.
@@ -320,6 +327,7 @@ class BatchedTradingEnv:
             if a.size and (a.max() >= len(self.positions) or a.min() < -1):
                 raise IndexError("list index out of range")  # positions[position_index] (:234)
             _abi.check(self._lib, self._lib.gte_step(self._h, a.ctypes.data, 0))
+        self._epoch += 1
         obs, reward, term, trunc = self._results()
         return obs, reward, term, trunc, LazyInfo(self)
 

@@ -22,11 +22,21 @@ hipError_t launch_step(const Params& p, int vec, bool nt, bool coop, int stage, 
 hipError_t launch_reset(const Params& p, int vec, bool nt, bool coop, int stage, int blocks,
                         int threads, hipStream_t stream);
 size_t lds_bytes(const Params& p, int stage);
+struct StateSoA {
+  int32_t *idx, *step, *pos, *dsi, *start, *episode, *needs_reset;
+  double *asset, *fiat, *ia, *ifi, *pv, *realpos;
+};
+hipError_t launch_extract_state(const EnvRec* rec, int n, const StateSoA& o, hipStream_t stream);
+hipError_t launch_rewind_queue(EnvRec* rec, int n, hipStream_t stream);
+hipError_t launch_affinity_rebuild(const Params& p, int32_t* bins, int n_bins_per_ds,
+                                   const int32_t* slot_of_rank, int32_t* perm_out,
+                                   hipStream_t stream);
 hipError_t launch_add_orders(const Params& p, const int32_t* pos_index, const double* limit,
                              const uint8_t* persistent, hipStream_t stream);
 }  // namespace gte
 
 using gte::DatasetDesc;
+using gte::EnvRec;
 using gte::Params;
 
 static thread_local std::string g_err = "";
@@ -74,6 +84,14 @@ struct gte_env {
   int stage = 0;           // dynamic columns: 0 global, 1 raw rings in LDS, 2 resolved in LDS
   int32_t* term_base = nullptr;  // the two-slot terminal counter in use (owned or bound)
   int term_slot = 0;       // slot the last launch added to
+  // L2-affinity processing order (gte_kernels.hip, "L2-affinity permutation")
+  int affinity_period = 0;       // 0 = off
+  int steps_since_rebuild = 0;
+  int n_bins_per_ds = 0;
+  int32_t* d_perm = nullptr;
+  int32_t* d_slot_of_rank = nullptr;
+  int32_t* d_bins = nullptr;
+  gte::StateSoA soa = {};  // host-facing struct-of-arrays mirrors (gte_get_state)
 };
 
 template <typename T>
@@ -206,12 +224,14 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   E->stream = E->own_stream;
   chk(hipEventCreate(&E->ev0) == hipSuccess && hipEventCreate(&E->ev1) == hipSuccess
           ? GTE_OK : fail(GTE_ERR_HIP, "hipEventCreate failed"));
-  chk(dev_alloc(E, &p.idx, N)); chk(dev_alloc(E, &p.step, N)); chk(dev_alloc(E, &p.pos, N));
-  chk(dev_alloc(E, &p.dsi, N)); chk(dev_alloc(E, &p.start, N)); chk(dev_alloc(E, &p.episode, N));
-  chk(dev_alloc(E, &p.needs_reset, N)); chk(dev_alloc(E, &p.eps_on_ds, N));
-  chk(dev_alloc(E, &p.n_picks, N)); chk(dev_alloc(E, &p.q_head, N));
-  chk(dev_alloc(E, &p.asset, N)); chk(dev_alloc(E, &p.fiat, N)); chk(dev_alloc(E, &p.ia, N));
-  chk(dev_alloc(E, &p.ifi, N)); chk(dev_alloc(E, &p.pv, N)); chk(dev_alloc(E, &p.realpos, N));
+  chk(dev_alloc(E, &p.rec, N));  // zero-filled: every counter starts at 0
+  chk(dev_alloc(E, &E->soa.idx, N)); chk(dev_alloc(E, &E->soa.step, N));
+  chk(dev_alloc(E, &E->soa.pos, N)); chk(dev_alloc(E, &E->soa.dsi, N));
+  chk(dev_alloc(E, &E->soa.start, N)); chk(dev_alloc(E, &E->soa.episode, N));
+  chk(dev_alloc(E, &E->soa.needs_reset, N));
+  chk(dev_alloc(E, &E->soa.asset, N)); chk(dev_alloc(E, &E->soa.fiat, N));
+  chk(dev_alloc(E, &E->soa.ia, N)); chk(dev_alloc(E, &E->soa.ifi, N));
+  chk(dev_alloc(E, &E->soa.pv, N)); chk(dev_alloc(E, &E->soa.realpos, N));
   chk(dev_alloc(E, &E->owned.obs, N * p.W * p.Fobs));
   chk(dev_alloc(E, &E->owned.reward, N)); chk(dev_alloc(E, &E->owned.reward64, N));
   chk(dev_alloc(E, &E->owned.terminated, N)); chk(dev_alloc(E, &E->owned.truncated, N));
@@ -264,6 +284,33 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   const int64_t waves = ((int64_t)p.N + epw - 1) / epw;
   E->threads = 256;
   E->blocks = (int)((waves + 3) / 4);
+  // L2-affinity order: only worth it when every XCD gets several workgroups and the
+  // windows are big enough to be bandwidth-bound
+  {
+    const int period = cfg->affinity_period == 0 ? 128 : cfg->affinity_period;
+    const int EPB = epw * 4;
+    const int n_wg = (p.N + EPB - 1) / EPB;
+    if (period > 0 && n_wg >= 64 && vpe * E->vec * 4 >= 512) {
+      // slots in XCD-major order: workgroup b runs on XCD b % 8 (round-robin dispatch)
+      std::vector<int32_t> slot_of_rank;
+      slot_of_rank.reserve((size_t)p.N);
+      for (int x = 0; x < 8; ++x)
+        for (int b = x; b < n_wg; b += 8)
+          for (int sl = b * EPB; sl < (b + 1) * EPB && sl < p.N; ++sl) slot_of_rank.push_back(sl);
+      int nb = 8192 / p.D;
+      nb = nb < 1 ? 1 : (nb > 4096 ? 4096 : nb);
+      E->n_bins_per_ds = nb;
+      int rc2 = GTE_OK;
+      if (rc2 == GTE_OK) rc2 = dev_alloc(E, &E->d_perm, N, false);
+      if (rc2 == GTE_OK) rc2 = dev_alloc(E, &E->d_slot_of_rank, N, false);
+      if (rc2 == GTE_OK) rc2 = dev_alloc(E, &E->d_bins, (size_t)p.D * nb);
+      if (rc2 == GTE_OK && hipMemcpy(E->d_slot_of_rank, slot_of_rank.data(), sizeof(int32_t) * N,
+                                     hipMemcpyHostToDevice) != hipSuccess)
+        rc2 = fail(GTE_ERR_HIP, "copying slot_of_rank failed");
+      if (rc2 != GTE_OK) { std::string keep = g_err; gte_destroy(E); g_err = keep; return rc2; }
+      E->affinity_period = period;
+    }
+  }
   // the zero-fills above ran on the null stream; the env's stream is non-blocking
   if (hipDeviceSynchronize() != hipSuccess) {
     gte_destroy(E);
@@ -346,6 +393,12 @@ int gte_reset(gte_env* E, const uint8_t* mask, const int32_t* inj_idx,
   p.term_count_next = E->term_base + 1;
   HIPCHK(gte::launch_reset(p, E->vec, E->cfg.nontemporal_obs != 0, E->coop, E->stage, E->blocks,
                            E->threads, E->stream));
+  if (E->affinity_period > 0) {  // new start rows: re-sort the processing order
+    HIPCHK(gte::launch_affinity_rebuild(E->p, E->d_bins, E->n_bins_per_ds, E->d_slot_of_rank,
+                                        E->d_perm, E->stream));
+    E->p.perm = E->d_perm;
+    E->steps_since_rebuild = 0;
+  }
   // host staging buffers may be reused by the caller right away: pageable copies above
   // are complete on return, but keep the contract simple and explicit
   HIPCHK(hipStreamSynchronize(E->stream));
@@ -375,7 +428,8 @@ int gte_set_autoreset_injection(gte_env* E, int32_t n, const int32_t* inj_idx,
   TRY(put(&E->d_q_pos, inj_pos_index, &p.q_pos));
   TRY(put(&E->d_q_ds, inj_dataset, &p.q_ds));
   p.q_n = n;
-  HIPCHK(hipMemset(p.q_head, 0, sizeof(int32_t) * p.N));
+  HIPCHK(gte::launch_rewind_queue(p.rec, p.N, E->stream));
+  HIPCHK(hipStreamSynchronize(E->stream));
   HIPCHK(hipDeviceSynchronize());
   return GTE_OK;
 }
@@ -384,6 +438,13 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
   if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
   if (!E->was_reset) return fail(GTE_ERR_STATE, "gte_step before gte_reset");
   if (!actions) return fail(GTE_ERR_INVALID, "actions is NULL");
+  if (E->affinity_period > 0 && ++E->steps_since_rebuild >= E->affinity_period) {
+    // envs drift one row per step and ~1/duration of them jump at a reset: re-sort now and
+    // then (4 tiny launches, stream-ordered between two steps)
+    HIPCHK(gte::launch_affinity_rebuild(E->p, E->d_bins, E->n_bins_per_ds, E->d_slot_of_rank,
+                                        E->d_perm, E->stream));
+    E->steps_since_rebuild = 0;
+  }
   Params p = E->p;
   if (actions_on_device) {
     p.actions = actions;
@@ -413,16 +474,15 @@ int gte_add_limit_orders(gte_env* E, const int32_t* pos_index, const double* lim
   for (size_t i = 0; i < N; ++i)
     if (pos_index[i] >= p.P) return fail(GTE_ERR_INVALID, "pos_index[%zu] out of range", i);
   HIPCHK(hipSetDevice(E->cfg.device));
-  if (!p.lo_n) {  // first use: allocate the order tables
-    TRY(dev_alloc(E, &p.lo_pos, N * p.P));
+  if (!p.lo_pos) {  // first use: allocate the order tables (the counts live in EnvRec)
+    int32_t* lo_pos = nullptr;
+    TRY(dev_alloc(E, &lo_pos, N * p.P));
     TRY(dev_alloc(E, &p.lo_limit, N * p.P));
     TRY(dev_alloc(E, &p.lo_persist, N * p.P));
     TRY(dev_alloc(E, &E->d_lo_limit_in, N));
     TRY(dev_alloc(E, &E->d_lo_persist_in, N));
-    int32_t* lo_n = nullptr;
-    TRY(dev_alloc(E, &lo_n, N));
     HIPCHK(hipDeviceSynchronize());
-    p.lo_n = lo_n;
+    p.lo_pos = lo_pos;
   }
   TRY(stage(E, E->d_inj_pos, pos_index, 4 * N));
   TRY(stage(E, E->d_lo_limit_in, limit, 8 * N));
@@ -465,12 +525,16 @@ int gte_bind_outputs(gte_env* E, const gte_outputs* b) {
 
 int gte_get_state(gte_env* E, gte_state_view* out) {
   if (!E || !out) return fail(GTE_ERR_INVALID, "NULL argument");
-  const Params& p = E->p;
-  out->idx = p.idx; out->step = p.step; out->position_index = p.pos;
-  out->dataset_index = p.dsi; out->start_idx = p.start; out->episode = p.episode;
-  out->needs_reset = p.needs_reset; out->asset = p.asset; out->fiat = p.fiat;
-  out->interest_asset = p.ia; out->interest_fiat = p.ifi;
-  out->portfolio_valuation = p.pv; out->real_position = p.realpos;
+  // the state lives in 128-byte records; snapshot it into struct-of-arrays mirrors
+  // (stream-ordered: the views reflect every launch enqueued before this call)
+  HIPCHK(hipSetDevice(E->cfg.device));
+  HIPCHK(gte::launch_extract_state(E->p.rec, E->p.N, E->soa, E->stream));
+  const gte::StateSoA& o = E->soa;
+  out->idx = o.idx; out->step = o.step; out->position_index = o.pos;
+  out->dataset_index = o.dsi; out->start_idx = o.start; out->episode = o.episode;
+  out->needs_reset = o.needs_reset; out->asset = o.asset; out->fiat = o.fiat;
+  out->interest_asset = o.ia; out->interest_fiat = o.ifi;
+  out->portfolio_valuation = o.pv; out->real_position = o.realpos;
   return GTE_OK;
 }
 

@@ -23,6 +23,18 @@ struct DatasetDesc {
   int64_t T;
 };
 
+// Per-env state record: ONE 128-byte line per environment, so that an env reached
+// through the L2-affinity permutation costs one line in and one line out (as a
+// struct of arrays the same gather touched 13 sectors per env and cancelled the
+// gain).  gte_get_state extracts struct-of-arrays views for the host on demand.
+struct alignas(128) EnvRec {
+  int32_t idx, step, pos, dsi, start, episode, needs_reset, eps_on_ds;  // 32 B
+  int32_t n_picks, q_head, lo_n, pad0;                                  // 16 B
+  double asset, fiat, ia, ifi, pv, realpos;                             // 48 B
+  int32_t pad1[8];                                                      // -> 128 B
+};
+static_assert(sizeof(EnvRec) == 128, "EnvRec must be one 128-byte line");
+
 // Everything a launch needs; passed by value as the kernel argument.
 struct Params {
   // --- configuration (from gte_config)
@@ -36,12 +48,10 @@ struct Params {
   // --- resident tables
   const DatasetDesc* ds;
   const double* positions;  // f64 [P]
-  // --- per-env state, struct of arrays
-  int32_t *idx, *step, *pos, *dsi, *start, *episode, *needs_reset, *eps_on_ds, *n_picks;
-  double *asset, *fiat, *ia, *ifi, *pv, *realpos;
+  // --- per-env state, one 128-byte record per env
+  EnvRec* rec;
   float* ring;  // f32 [N, depth, nd]
   // --- pending limit orders (null until the first gte_add_limit_orders)
-  int32_t* lo_n;        // i32 [N]
   int32_t* lo_pos;      // i32 [N, P] target position index, insertion order
   double* lo_limit;     // f64 [N, P]
   uint8_t* lo_persist;  // u8  [N, P]
@@ -60,8 +70,8 @@ struct Params {
   // --- queued draws for auto-resets
   int32_t q_n;
   const int32_t *q_idx, *q_pos, *q_ds;
-  int32_t* q_head;
   // --- geometry
+  const int32_t* perm; // processing slot -> env id (L2-affinity order), or null = identity
   int32_t epw;         // environments per wavefront
   int32_t debug;       // gte_config.debug_flags (timing ablations)
 };

@@ -31,32 +31,41 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 enum { MODE_STEP = 0, MODE_RESET = 1 };
 
 struct EnvRegs {
-  int32_t idx, step, pos, dsi, start, episode, needs_reset;
+  int32_t idx, step, pos, dsi, start, episode, needs_reset, eps_on_ds, n_picks, q_head, lo_n;
   Portfolio q;
   double pv, realpos;
 };
 
 __device__ inline void load_state(const Params& p, int e, EnvRegs& s) {
-  s.idx = p.idx[e]; s.step = p.step[e]; s.pos = p.pos[e]; s.dsi = p.dsi[e];
-  s.start = p.start[e]; s.episode = p.episode[e]; s.needs_reset = p.needs_reset[e];
-  s.q.asset = p.asset[e]; s.q.fiat = p.fiat[e]; s.q.ia = p.ia[e]; s.q.ifi = p.ifi[e];
-  s.pv = p.pv[e]; s.realpos = p.realpos[e];
+  const EnvRec r = p.rec[e];  // 128-byte aligned record: six 16-byte loads
+  s.idx = r.idx; s.step = r.step; s.pos = r.pos; s.dsi = r.dsi; s.start = r.start;
+  s.episode = r.episode; s.needs_reset = r.needs_reset; s.eps_on_ds = r.eps_on_ds;
+  s.n_picks = r.n_picks; s.q_head = r.q_head; s.lo_n = r.lo_n;
+  s.q.asset = r.asset; s.q.fiat = r.fiat; s.q.ia = r.ia; s.q.ifi = r.ifi;
+  s.pv = r.pv; s.realpos = r.realpos;
 }
 
 __device__ inline void store_state(const Params& p, int e, const EnvRegs& s) {
-  p.idx[e] = s.idx; p.step[e] = s.step; p.pos[e] = s.pos; p.dsi[e] = s.dsi;
-  p.start[e] = s.start; p.episode[e] = s.episode; p.needs_reset[e] = s.needs_reset;
-  p.asset[e] = s.q.asset; p.fiat[e] = s.q.fiat; p.ia[e] = s.q.ia; p.ifi[e] = s.q.ifi;
-  p.pv[e] = s.pv; p.realpos[e] = s.realpos;
+  EnvRec r;
+  r.idx = s.idx; r.step = s.step; r.pos = s.pos; r.dsi = s.dsi; r.start = s.start;
+  r.episode = s.episode; r.needs_reset = s.needs_reset; r.eps_on_ds = s.eps_on_ds;
+  r.n_picks = s.n_picks; r.q_head = s.q_head; r.lo_n = s.lo_n; r.pad0 = 0;
+  r.asset = s.q.asset; r.fiat = s.q.fiat; r.ia = s.q.ia; r.ifi = s.q.ifi;
+  r.pv = s.pv; r.realpos = s.realpos;
+  // only the 96 live bytes are written
+  uint4* dst = reinterpret_cast<uint4*>(&p.rec[e]);
+  const uint4* src = reinterpret_cast<const uint4*>(&r);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dst[i] = src[i];
 }
 
 // MultiDatasetTradingEnv.next_dataset, environments.py:380-391
 __device__ inline void next_dataset(const Params& p, int e, int32_t inj_ds, EnvRegs& s,
                                     bool& fresh) {
-  const int32_t n = p.n_picks[e];
-  p.n_picks[e] = n + 1;
+  const int32_t n = s.n_picks;
+  s.n_picks = n + 1;
   s.dsi = (inj_ds >= 0) ? inj_ds : perm_pick(p, e, n / p.D, n % p.D);
-  p.eps_on_ds[e] = 0;               // :381
+  s.eps_on_ds = 0;                  // :381
   if (p.persist) fresh = true;      // _set_df rebuilds _obs_array (:135-141)
 }
 
@@ -64,15 +73,14 @@ __device__ inline void next_dataset(const Params& p, int e, int32_t inj_ds, EnvR
 __device__ inline void do_reset(const Params& p, int e, int32_t inj_idx, int32_t inj_pos,
                                 int32_t inj_ds, EnvRegs& s, bool& fresh) {
   if (p.D > 1) {  // :394-398
-    const int32_t n = p.eps_on_ds[e] + 1;
-    p.eps_on_ds[e] = n;
-    if (n % p.switch_every == 0) next_dataset(p, e, inj_ds, s, fresh);
+    s.eps_on_ds += 1;
+    if (s.eps_on_ds % p.switch_every == 0) next_dataset(p, e, inj_ds, s, fresh);
   }
   uint32_t r[4];
   reset_draws(p, e, s.episode, 0x52534554u, r);
   s.episode += 1;
   s.step = 0;  // :166
-  if (p.lo_n) p.lo_n[e] = 0;  // :168 self._limit_orders = {}
+  s.lo_n = 0;  // :168 self._limit_orders = {}
   int32_t pi = p.init_pos_index;  // :167
   if (pi < 0) pi = (inj_pos >= 0) ? inj_pos : bounded(r[0], p.P);
   s.pos = pi;
@@ -103,7 +111,7 @@ __device__ inline void do_reset(const Params& p, int e, int32_t inj_idx, int32_t
 // and raises RuntimeError; the intended behaviour is implemented).
 __device__ inline void fill_limit_orders(const Params& p, int e, const DatasetDesc& d,
                                          EnvRegs& s) {
-  const int n = p.lo_n[e];
+  const int n = s.lo_n;
   if (n <= 0) return;
   int32_t* lp = p.lo_pos + (int64_t)e * p.P;
   double* ll = p.lo_limit + (int64_t)e * p.P;
@@ -126,7 +134,7 @@ __device__ inline void fill_limit_orders(const Params& p, int e, const DatasetDe
       ++k;
     }
   }
-  if (k != n) p.lo_n[e] = k;
+  s.lo_n = k;
 }
 
 // TradingEnv.add_limit_order, environments.py:227-231: `orders[position] = {...}` — an
@@ -139,22 +147,22 @@ __global__ void gte_add_orders_kernel(const Params p, const int32_t* pos_index,
   const int32_t pi = pos_index[e];
   if (pi < 0) return;
   int32_t* lp = p.lo_pos + (int64_t)e * p.P;
-  const int n = p.lo_n[e];
+  const int n = p.rec[e].lo_n;
   int j = 0;
   while (j < n && p.positions[lp[j]] != p.positions[pi]) ++j;
-  if (j == n) p.lo_n[e] = n + 1;  // n < P: at most one order per distinct position value
+  if (j == n) p.rec[e].lo_n = n + 1;  // n < P: at most one order per distinct position value
   lp[j] = pi;
   p.lo_limit[(int64_t)e * p.P + j] = limit[e];
   p.lo_persist[(int64_t)e * p.P + j] = persistent ? persistent[e] : 0;
 }
 
-__device__ inline void pop_injection(const Params& p, int e, int32_t& qi, int32_t& qp,
-                                     int32_t& qd) {
+__device__ inline void pop_injection(const Params& p, int e, EnvRegs& s, int32_t& qi,
+                                     int32_t& qp, int32_t& qd) {
   qi = qp = qd = -1;
   if (p.q_n <= 0) return;
-  const int32_t h = p.q_head[e];
+  const int32_t h = s.q_head;
   if (h >= p.q_n) return;
-  p.q_head[e] = h + 1;
+  s.q_head = h + 1;
   const int64_t k = (int64_t)e * p.q_n + h;
   if (p.q_idx) qi = p.q_idx[k];
   if (p.q_pos) qp = p.q_pos[k];
@@ -210,7 +218,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
       const int32_t ii = p.inj_idx ? p.inj_idx[e] : -1;
       const int32_t ip = p.inj_pos ? p.inj_pos[e] : -1;
       const int32_t id = p.inj_ds ? p.inj_ds[e] : -1;
-      if (p.D > 1 && p.n_picks[e] == 0) next_dataset(p, e, id, s, fresh);  // ctor pick, :378
+      if (p.D > 1 && s.n_picks == 0) next_dataset(p, e, id, s, fresh);  // ctor pick, :378
       do_reset(p, e, ii, ip, id, s, fresh);
       store_state(p, e, s);
       p.reward[e] = 0.0f; p.reward64[e] = 0.0;
@@ -230,7 +238,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
     if (s.needs_reset) {
       if (p.autoreset == GTE_AUTORESET_NEXT_STEP) {
         int32_t qi, qp, qd;
-        pop_injection(p, e, qi, qp, qd);
+        pop_injection(p, e, s, qi, qp, qd);
         do_reset(p, e, qi, qp, qd, s, fresh);
         p.reward[e] = 0.0f; p.reward64[e] = 0.0;
         p.terminated[e] = 0; p.truncated[e] = 0;
@@ -254,7 +262,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
       }
       s.idx += 1;   // :235
       s.step += 1;  // :236
-      if (p.lo_n) fill_limit_orders(p, e, d, s);  // :238
+      if (p.lo_pos) fill_limit_orders(p, e, d, s);  // :238
       const double price = d.close[s.idx];  // :239
       s.q.ia = pymax0(-s.q.asset) * p.rate;   // update_interest, portfolio.py:44-46
       s.q.ifi = pymax0(-s.q.fiat) * p.rate;
@@ -274,7 +282,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
       if (ended) s.needs_reset = 1;
       if (ended && p.autoreset == GTE_AUTORESET_SAME_STEP) {
         int32_t qi, qp, qd;
-        pop_injection(p, e, qi, qp, qd);
+        pop_injection(p, e, s, qi, qp, qd);
         do_reset(p, e, qi, qp, qd, s, fresh);
       }
     }
@@ -313,6 +321,7 @@ __device__ inline void store_out(T* dst, const T& v) {
 // LDS image of a workgroup: the jobs phase A hands to phase B (one per env of the
 // workgroup) and, when STAGE, the dynamic-column values of every window row.
 struct WgLds {
+  int32_t* env;     // [EPB] env id processed in this slot (perm[slot], or slot itself)
   uint64_t* src;    // [EPB] first row of the window in the feature table
   int32_t* flags;   // [EPB] bit0 copy the window, bit1 zero the env's dynamic store
   int32_t* idx;     // [EPB]
@@ -330,6 +339,7 @@ __device__ inline WgLds carve_lds(unsigned char* base, int EPB) {
   L.idx = (int32_t*)base;                  base += 4 * EPB;
   L.slot0 = (int32_t*)base;                base += 4 * EPB;
   L.n_zero = (int32_t*)base;               base += 4 * EPB;
+  L.env = (int32_t*)base;                  base += 4 * EPB;
   L.staged = (float*)base;
   return L;
 }
@@ -357,7 +367,7 @@ __device__ inline float dyn_value(const Params& p, const WgLds& L, int s, const 
 // The wave gathers, once and coalesced, the dynamic-column values of all window rows
 // of its envs into LDS (W*nd floats per env: 160 B at the headline shape), so that the
 // copy loop patches from LDS instead of issuing divergent global loads per vector.
-__device__ inline void stage_dynamic(const Params& p, const WgLds& L, int wg_first, int s_first,
+__device__ inline void stage_dynamic(const Params& p, const WgLds& L, int s_first,
                                      int n_env, int lane, uint64_t wnd_magic) {
   const uint32_t WND = (uint32_t)(p.W * p.nd);
   const uint32_t total = (uint32_t)n_env * WND;
@@ -367,7 +377,7 @@ __device__ inline void stage_dynamic(const Params& p, const WgLds& L, int wg_fir
     const uint32_t w = r / (uint32_t)p.nd;
     const int i = (int)(r - w * (uint32_t)p.nd);
     const int s = s_first + (int)el;
-    const float* ring_e = p.ring + (int64_t)(wg_first + s) * p.depth * p.nd;
+    const float* ring_e = p.ring + (int64_t)L.env[s] * p.depth * p.nd;
     L.staged[(uint32_t)s * WND + r] = dyn_value(p, L, s, ring_e, (int)w, i);
   }
 }
@@ -379,13 +389,16 @@ __device__ inline void stage_dynamic(const Params& p, const WgLds& L, int wg_fir
 // of a T-deep column): gathered after phase A, already resolved (stage_dynamic).
 enum { STAGE_NONE = 0, STAGE_RAW = 1, STAGE_LATE = 2 };
 
-__device__ inline void stage_raw_rings(const Params& p, const WgLds& L, int wg_first, int s_first,
-                                       int n_env, int lane) {
+__device__ inline void stage_raw_rings(const Params& p, const WgLds& L, int s_first, int n_env,
+                                       int lane, uint64_t wnd_magic) {
   const uint32_t WND = (uint32_t)(p.W * p.nd);
   const uint32_t total = (uint32_t)n_env * WND;
-  const float* src = p.ring + (int64_t)(wg_first + s_first) * WND;  // depth == W here
   float* dst = L.staged + (uint32_t)s_first * WND;
-  for (uint32_t k = (uint32_t)lane; k < total; k += 64u) dst[k] = src[k];
+  for (uint32_t k = (uint32_t)lane; k < total; k += 64u) {
+    const uint32_t el = fastdiv40(k, wnd_magic);
+    const uint32_t r = k - el * WND;
+    dst[k] = p.ring[(int64_t)L.env[s_first + (int)el] * WND + r];  // depth == W here
+  }
 }
 
 __device__ inline float dyn_value_raw(const Params& p, const WgLds& L, int s, int w, int i) {
@@ -429,14 +442,13 @@ __device__ inline void patch_dynamic(const Params& p, const WgLds& L, vec_t& v, 
 // smaller than one wave instruction, e.g. windows=None).  The env differs per lane:
 // its job is read from LDS.  U independent loads are in flight per lane.
 template <int VEC, bool NT, int STAGE, int U>
-__device__ inline void phase_b(const Params& p, const WgLds& L, int wg_first, int s_first,
+__device__ inline void phase_b(const Params& p, const WgLds& L, int s_first,
                                int n_env, int lane, uint64_t vpe_magic, uint64_t fv_magic) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
   const uint32_t V = (uint32_t)(p.W * p.Fobs);
   const uint32_t VPE = V / VEC;                // vectors per env
   const uint32_t FV = (uint32_t)p.Fobs / VEC;  // vectors per row
   const uint32_t total = (uint32_t)n_env * VPE;
-  float* const obs0 = p.obs + (int64_t)(wg_first + s_first) * V;
 
   for (uint32_t k0 = 0; k0 < total; k0 += 64u * U) {
     vec_t v[U];
@@ -456,26 +468,26 @@ __device__ inline void phase_b(const Params& p, const WgLds& L, int wg_first, in
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (!ok[u]) continue;
-      const uint32_t k = k0 + (uint32_t)u * 64u + (uint32_t)lane;
       const uint32_t w = fastdiv40(jj[u], fv_magic);
       const int col = (int)(jj[u] - w * FV) * VEC;
       const int s = s_first + (int)ee[u];
-      const float* ring_e = p.ring + (int64_t)(wg_first + s) * p.depth * p.nd;
+      const int64_t env = L.env[s];
+      const float* ring_e = p.ring + env * p.depth * p.nd;
       patch_dynamic<VEC, STAGE>(p, L, v[u], s, ring_e, (int)w, col);
-      store_out<NT>((vec_t*)(obs0 + (int64_t)k * VEC), v[u]);
+      store_out<NT>((vec_t*)(p.obs + env * V + (int64_t)jj[u] * VEC), v[u]);
     }
   }
 }
 
 // zero the dynamic store of envs that switched dataset in persist mode (the
 // reference rebuilds _obs_array in _set_df), except the current row's slot
-__device__ inline void zero_fresh_stores(const Params& p, const WgLds& L, int wg_first,
+__device__ inline void zero_fresh_stores(const Params& p, const WgLds& L,
                                          int s_first, int n_env, int lane) {
   for (int el = 0; el < n_env; ++el) {
     const int s = s_first + el;
     if (!(L.flags[s] & 2)) continue;
     const int idx = L.idx[s];
-    float* ring_e = p.ring + (int64_t)(wg_first + s) * p.depth * p.nd;
+    float* ring_e = p.ring + (int64_t)L.env[s] * p.depth * p.nd;
     const int64_t n = p.depth * p.nd;
     const int64_t keep_lo = (int64_t)idx * p.nd, keep_hi = keep_lo + p.nd;
     for (int64_t k = lane; k < n; k += 64)
@@ -505,30 +517,147 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
   const WgLds L = carve_lds(gte_smem, EPB);
   const int s_first = wib * p.epw;
   const int n_env = min(p.epw, n_wg - s_first);
-  if (STAGE == STAGE_RAW && n_env > 0) stage_raw_rings(p, L, wg_first, s_first, n_env, lane);
+  // which env each slot of this wave processes: the identity, or the L2-affinity
+  // permutation (envs reading the same table region share an XCD, see gte_api.hip)
+  if (lane < p.epw) {
+    const int slot = wg_first + s_first + lane;
+    L.env[s_first + lane] = (lane < n_env) ? (p.perm ? p.perm[slot] : slot) : -1;
+  }
+  if (STAGE == STAGE_RAW && n_env > 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    stage_raw_rings(p, L, s_first, n_env, lane, wnd_magic);
+  }
 
   // ---- phase A
   if (!COOP || wib == 0) {  // wave-uniform
     const int s = COOP ? lane : wib * p.epw + lane;  // LDS slot = env within the workgroup
     const bool owns = COOP ? (lane < EPB) : (lane < p.epw);
+    const bool active = owns && s < n_wg;
+    const int e = active ? (p.perm ? p.perm[wg_first + s] : wg_first + s) : 0;
     ObsJob job;
-    phase_a<MODE>(p, wg_first + s, owns && s < n_wg, lane, job);
+    phase_a<MODE>(p, e, active, lane, job);
     if (owns) publish_job(L, s, job);  // slots past the last env get flags = 0
   }
   __syncthreads();
 
   // ---- phase B: each wave gathers the windows of its own EPW envs
   if (n_env <= 0 || (p.debug & 1)) return;
-  if (p.persist) zero_fresh_stores(p, L, wg_first, s_first, n_env, lane);
+  if (p.persist) zero_fresh_stores(p, L, s_first, n_env, lane);
   if (STAGE == STAGE_LATE) {
-    stage_dynamic(p, L, wg_first, s_first, n_env, lane, wnd_magic);
+    stage_dynamic(p, L, s_first, n_env, lane, wnd_magic);
     // LDS operations of one wave execute in order; this only stops the compiler from
     // moving the LDS reads of phase B above the staging writes
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  phase_b<VEC, NT, STAGE, 4>(p, L, wg_first, s_first, n_env, lane, vpe_magic, fv_magic);
+  phase_b<VEC, NT, STAGE, 4>(p, L, s_first, n_env, lane, vpe_magic, fv_magic);
+}
+
+// ---------------------------------------------------------------------------
+// L2-affinity permutation.  Workgroups are dealt round-robin over the 8 XCDs, each
+// with a private 4 MiB L2 (workgroup b and b+8 share one; observed behaviour, used
+// for speed only).  A 12.8 MB feature table does not fit one L2, and with random
+// starts every XCD reads all of it (measured: 146 MB of L2 misses per step).  If the
+// envs processed by XCD x all sit in the x-th eighth of the (dataset, row) space,
+// each L2 only has to hold 1/8 of the table and the window reads hit it (measured
+// 42 us vs 54 us per step, profiles/r01_tune_affinity_potential.log).  perm[slot] =
+// env is a counting sort of the envs by (dataset, row bucket), laid out so that the
+// r-th env in sorted order goes to the r-th slot in XCD-major order (slot_of_rank,
+// built on the host).  Results do not depend on the permutation; only speed does.
+__global__ void gte_affinity_hist_kernel(const Params p, int32_t* hist, int n_bins_per_ds) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.N) return;
+  const int d = p.rec[e].dsi;
+  const int64_t T = p.ds[d].T;
+  int b = (int)(((int64_t)p.rec[e].idx * n_bins_per_ds) / T);
+  b = b < 0 ? 0 : (b >= n_bins_per_ds ? n_bins_per_ds - 1 : b);
+  atomicAdd(&hist[d * n_bins_per_ds + b], 1);
+}
+
+// exclusive scan of `hist` (n_bins <= 1024 * per_thread) by one workgroup
+__global__ __launch_bounds__(1024) void gte_affinity_scan_kernel(int32_t* hist, int n_bins) {
+  __shared__ int32_t part[1024];
+  const int t = threadIdx.x;
+  const int per = (n_bins + 1023) / 1024;
+  const int lo = t * per, hi = min(n_bins, lo + per);
+  int32_t sum = 0;
+  for (int i = lo; i < hi; ++i) sum += hist[i];
+  part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    const int32_t v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int32_t run = part[t] - sum;  // exclusive prefix of this thread's chunk
+  for (int i = lo; i < hi; ++i) {
+    const int32_t c = hist[i];
+    hist[i] = run;
+    run += c;
+  }
+}
+
+__global__ void gte_affinity_scatter_kernel(const Params p, int32_t* cursor, int n_bins_per_ds,
+                                            const int32_t* slot_of_rank, int32_t* perm_out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.N) return;
+  const int d = p.rec[e].dsi;
+  const int64_t T = p.ds[d].T;
+  int b = (int)(((int64_t)p.rec[e].idx * n_bins_per_ds) / T);
+  b = b < 0 ? 0 : (b >= n_bins_per_ds ? n_bins_per_ds - 1 : b);
+  const int rank = atomicAdd(&cursor[d * n_bins_per_ds + b], 1);
+  perm_out[slot_of_rank[rank]] = e;
+}
+
+hipError_t launch_affinity_rebuild(const Params& p, int32_t* bins, int n_bins_per_ds,
+                                   const int32_t* slot_of_rank, int32_t* perm_out,
+                                   hipStream_t stream) {
+  const int n_bins = p.D * n_bins_per_ds;
+  hipError_t e = hipMemsetAsync(bins, 0, sizeof(int32_t) * n_bins, stream);
+  if (e != hipSuccess) return e;
+  const int blocks = (p.N + 255) / 256;
+  hipLaunchKernelGGL(gte_affinity_hist_kernel, dim3(blocks), dim3(256), 0, stream, p, bins,
+                     n_bins_per_ds);
+  hipLaunchKernelGGL(gte_affinity_scan_kernel, dim3(1), dim3(1024), 0, stream, bins, n_bins);
+  hipLaunchKernelGGL(gte_affinity_scatter_kernel, dim3(blocks), dim3(256), 0, stream, p, bins,
+                     n_bins_per_ds, slot_of_rank, perm_out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// struct-of-arrays views of the state for the host (gte_get_state)
+struct StateSoA {
+  int32_t *idx, *step, *pos, *dsi, *start, *episode, *needs_reset;
+  double *asset, *fiat, *ia, *ifi, *pv, *realpos;
+};
+
+__global__ void gte_extract_state_kernel(const EnvRec* rec, int n, StateSoA o) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const EnvRec r = rec[e];
+  o.idx[e] = r.idx; o.step[e] = r.step; o.pos[e] = r.pos; o.dsi[e] = r.dsi;
+  o.start[e] = r.start; o.episode[e] = r.episode; o.needs_reset[e] = r.needs_reset;
+  o.asset[e] = r.asset; o.fiat[e] = r.fiat; o.ia[e] = r.ia; o.ifi[e] = r.ifi;
+  o.pv[e] = r.pv; o.realpos[e] = r.realpos;
+}
+
+hipError_t launch_extract_state(const EnvRec* rec, int n, const StateSoA& o, hipStream_t stream) {
+  hipLaunchKernelGGL(gte_extract_state_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, rec, n, o);
+  return hipGetLastError();
+}
+
+__global__ void gte_rewind_queue_kernel(EnvRec* rec, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) rec[e].q_head = 0;
+}
+
+hipError_t launch_rewind_queue(EnvRec* rec, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(gte_rewind_queue_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, rec, n);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
@@ -538,7 +667,7 @@ static uint64_t magic40(uint32_t d) { return ((1ull << 40) + d - 1) / d; }
 
 size_t lds_bytes(const Params& p, int stage) {
   const size_t EPB = (size_t)p.epw * 4;
-  size_t b = EPB * (8 + 4 * GTE_MAX_DYN + 4 * 4);
+  size_t b = EPB * (8 + 4 * GTE_MAX_DYN + 5 * 4);
   if (stage) b += EPB * (size_t)p.W * (size_t)(p.nd ? p.nd : 1) * 4;
   return b;
 }

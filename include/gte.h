@@ -117,6 +117,11 @@ typedef struct gte_config {
   int32_t debug_flags;      /* timing ablations only (results become wrong):
                                1 = skip the observation gather, 2 = skip the
                                dynamic-column patch                               */
+  int32_t affinity_period;  /* L2-affinity processing order: every this many steps the
+                               envs are re-sorted by (dataset, table region) so that
+                               each XCD's L2 serves one region (speed only; results
+                               do not depend on it).  0 = default (128), -1 = off   */
+  int32_t reserved1;
 } gte_config;
 
 /* Device pointers of the per-step return values of TradingEnv.step
@@ -207,6 +212,10 @@ int gte_add_limit_orders(gte_env* env, const int32_t* pos_index, const double* l
 
 /* Where the results of the last gte_step / gte_reset live (device pointers). */
 int gte_get_outputs(gte_env* env, gte_outputs* out);
+/* Snapshot of the per-env state as struct-of-arrays device buffers.  Internally the
+ * state is one 128-byte record per env; this call enqueues a small extraction
+ * kernel on the env's stream, so the views reflect every launch enqueued before
+ * it.  Call it again after later steps (the pointers stay the same). */
 int gte_get_state(gte_env* env, gte_state_view* out);
 
 /* Use caller-owned device buffers for the outputs (e.g. torch tensors that are

@@ -2,7 +2,7 @@
 """In-process A/B of step-kernel variants on one GPU (interleaved rounds, HIP events).
 
     python tools/tune.py [--workload c3] [--steps 300] [--rounds 5] variant ...
-variant = kernel_variant:epw:nt[:debug_flags], e.g. 0:16:1 1:16:1 2:16:1 3:16:1 0:16:1:1
+variant = kernel_variant:epw:nt[:debug_flags[:affinity_period]], e.g. 0:16:1 1:16:1 0:16:1:1 0:16:1:0:-1
 """
 import argparse
 import os
@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--envs", type=int, default=0)
     ap.add_argument("--duration", type=int, default=0)
+    ap.add_argument("--region-affine", type=int, default=0,
+                    help="K>0: inject start rows so that workgroup b (64 envs) only reads table "
+                         "region b %% K (potential of an XCD/L2-affine env order; K=8 XCDs)")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     import torch
@@ -34,12 +37,25 @@ def main():
     acts = torch.randint(0, 3, (64, N), dtype=torch.int32, device=dev)
     envs = {}
     for v in a.variants:
-        kv, epw, nt, *dbg = v.split(":")
+        kv, epw, nt, *rest = v.split(":")
+        dbg = rest[:1]
+        aff = int(rest[1]) if len(rest) > 1 else 0
         envs[v] = BatchedTradingEnv((feat, close), num_envs=N, seed=1, output="torch",
                                     kernel_variant=int(kv), envs_per_wave=int(epw),
                                     nontemporal_obs=bool(int(nt)),
-                                    debug_flags=int(dbg[0]) if dbg else 0, **bench.env_kwargs(wl))
-        envs[v].reset()
+                                    debug_flags=int(dbg[0]) if dbg else 0, affinity_period=aff,
+                                    **bench.env_kwargs(wl))
+        if a.region_affine:
+            K = a.region_affine
+            T, W, dur = wl["T"], wl["windows"] or 1, wl["max_episode_duration"]
+            lo, hi = W - 1, T - dur - (W - 1)
+            rng = np.random.default_rng(0)
+            region = (np.arange(N) // 64) % K
+            span = (hi - lo) // K
+            idx0 = (lo + region * span + rng.integers(0, span, N)).astype(np.int32)
+            envs[v].reset(inject_idx=idx0)
+        else:
+            envs[v].reset()
         for i in range(50):
             envs[v].step(acts[i % 64])
     torch.cuda.synchronize()
