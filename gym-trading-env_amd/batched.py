@@ -62,6 +62,12 @@ class LazyInfo(dict):
 
     def __missing__(self, key):
         e = self._env
+        if key.startswith("_") and key[1:] in self._KEYS:
+            # Gymnasium's vector-env convention (docs/source/vectorize_env.rst:25-33): `_key`
+            # marks the envs for which `key` is present — here always all of them
+            v = np.ones(e.num_envs, dtype=bool)
+            self[key] = v
+            return v
         if key in ("idx", "step", "position_index", "real_position", "portfolio_valuation",
                    "dataset_index"):
             v = e.state(key)

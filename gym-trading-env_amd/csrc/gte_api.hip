@@ -7,6 +7,7 @@
 // point that needs one fails with GTE_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -370,6 +371,32 @@ static int finalize(gte_env* E) {
   return GTE_OK;
 }
 
+// injected draws come from the caller: refuse values the kernel would use as
+// out-of-range row / position / dataset indices
+static int check_injection(const gte_env* E, size_t count, const int32_t* idx, const int32_t* pos,
+                           const int32_t* ds) {
+  const Params& p = E->p;
+  int64_t maxT = 0, minT = INT64_MAX;
+  for (int d = 0; d < p.D; ++d) {
+    if (E->h_ds[d].T > maxT) maxT = E->h_ds[d].T;
+    if (E->h_ds[d].T > 0 && E->h_ds[d].T < minT) minT = E->h_ds[d].T;
+  }
+  const int64_t idx0 = p.has_window ? p.W - 1 : 0;
+  for (size_t i = 0; i < count; ++i) {
+    if (pos && pos[i] >= p.P) return fail(GTE_ERR_INVALID, "injected position index %d >= %d", pos[i], p.P);
+    if (ds && ds[i] >= p.D) return fail(GTE_ERR_INVALID, "injected dataset %d >= %d", ds[i], p.D);
+    if (idx && idx[i] >= 0) {
+      // an env needs at least one row after its start row; its dataset is known only when
+      // it is injected too, otherwise the shortest dataset bounds it
+      const int64_t T = (ds && ds[i] >= 0) ? E->h_ds[ds[i]].T : minT;
+      if (idx[i] < idx0 || idx[i] > T - 2)
+        return fail(GTE_ERR_INVALID, "injected start row %d outside [%lld, %lld]", idx[i],
+                    (long long)idx0, (long long)(T - 2));
+    }
+  }
+  return GTE_OK;
+}
+
 static int stage(gte_env* E, void* dst, const void* src, size_t bytes) {
   HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, E->stream));
   return GTE_OK;
@@ -380,6 +407,7 @@ int gte_reset(gte_env* E, const uint8_t* mask, const int32_t* inj_idx,
   if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
   HIPCHK(hipSetDevice(E->cfg.device));
   TRY(finalize(E));
+  TRY(check_injection(E, (size_t)E->p.N, inj_idx, inj_pos_index, inj_dataset));
   Params p = E->p;
   const size_t N = (size_t)p.N;
   p.mask = nullptr; p.inj_idx = p.inj_pos = p.inj_ds = nullptr;
@@ -410,6 +438,9 @@ int gte_set_autoreset_injection(gte_env* E, int32_t n, const int32_t* inj_idx,
                                 const int32_t* inj_pos_index, const int32_t* inj_dataset) {
   if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
   if (n < 0) return fail(GTE_ERR_INVALID, "n_episodes must be >= 0");
+  for (int d = 0; d < E->p.D; ++d)
+    if (E->h_ds[d].T <= 0) return fail(GTE_ERR_STATE, "upload every dataset before queueing draws");
+  TRY(check_injection(E, (size_t)E->p.N * (size_t)n, inj_idx, inj_pos_index, inj_dataset));
   HIPCHK(hipSetDevice(E->cfg.device));
   HIPCHK(hipStreamSynchronize(E->stream));
   Params& p = E->p;

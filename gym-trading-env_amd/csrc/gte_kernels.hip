@@ -232,7 +232,10 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
   if (active) {
     EnvRegs s;
     load_state(p, e, s);
-    const int32_t action = p.actions[e];
+    int32_t action = p.actions[e];
+    // positions[position_index] raises IndexError in the reference (:234); a device-side
+    // action cannot raise, so an out-of-range index is treated as None (hold), never read
+    if (action >= p.P) action = -1;
     bool fresh = false;
     bool stepped = true;
     if (s.needs_reset) {

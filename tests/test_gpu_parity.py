@@ -223,3 +223,46 @@ def test_limit_orders_need_high_low():
     with pytest.raises(GteError, match="high/low"):
         env.add_limit_order(np.zeros(8, np.int32), c[:8], True)
     env.close()
+
+
+def test_affinity_order_does_not_change_results(oracle_mod):
+    """The L2-affinity processing order is rebuilt every step here (period 1); outputs must
+    equal the identity order and the oracle."""
+    ds = [_synthetic(61, 5000, 30, sigma=5e-3)]
+    kw = dict(windows=20, positions=[-1, 0, 1], trading_fees=1e-4, borrow_interest_rate=3e-6,
+              max_episode_duration=30, autoreset="next_step")
+    _compare_with_oracle(oracle_mod, ds, n_envs=8192, steps=70, seed=31, check_every=7,
+                         affinity_period=1, **kw)
+    _compare_with_oracle(oracle_mod, ds, n_envs=8192, steps=70, seed=31, check_every=7,
+                         affinity_period=-1, **kw)
+
+
+def test_out_of_range_device_action_is_a_hold():
+    import torch
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    f, c = _synthetic(62, 200, 2)
+    env = BatchedTradingEnv((f, c), num_envs=256, positions=[0, 1], output="torch", seed=1)
+    env.reset()
+    before = env.state("position_index").copy()
+    bad = torch.full((256,), 1000, dtype=torch.int32, device="cuda")
+    env.step(bad)
+    np.testing.assert_array_equal(env.state("position_index"), before)
+    with pytest.raises(IndexError):
+        env.step(np.full(256, 2, np.int32))       # host actions are range-checked like :234
+    env.close()
+
+
+def test_injection_is_validated():
+    from gym_trading_env_amd import GteError
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    f, c = _synthetic(63, 100, 2)
+    env = BatchedTradingEnv((f, c), num_envs=4, positions=[0, 1], windows=5,
+                            max_episode_duration=20, output="numpy")
+    with pytest.raises(GteError, match="start row"):
+        env.reset(inject_idx=[10, 10, 99, 10])
+    with pytest.raises(GteError, match="position index"):
+        env.reset(inject_position_index=[0, 5, 0, 0])
+    env.reset(inject_idx=[4, 50, 98, 10], inject_position_index=[0, 1, 0, 1])
+    info_keys = env.step(np.zeros(4, np.int32))[4]
+    assert info_keys["_portfolio_valuation"].all() and "idx" in info_keys
+    env.close()
