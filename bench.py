@@ -215,7 +215,7 @@ def main():
             "metric": "env-steps/sec", "value": world * N * args.steps / el, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64 state / f32 obs", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {N} envs/GPU x obs ({W},{F_obs}) f32, "
                                    f"{D} dataset(s)/GPU of T={wl['T']}, positions [-1,0,1], fees 1e-4, borrow 3e-6, "
                                    f"max_episode_duration {wl['max_episode_duration']}, next-step autoreset",

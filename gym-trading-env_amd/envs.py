@@ -137,6 +137,16 @@ class TradingEnv(_EnvBase):
                 "borrowed_asset": max(0, -s["asset"]), "borrowed_fiat": max(0, -s["fiat"]),
                 "interest_asset": s["interest_asset"], "interest_fiat": s["interest_fiat"]}
 
+    def _row(self, position_index, real_position, valuation):
+        """One History row; the column set and order the reference logs (:186-197, :253-264)."""
+        t = self._idx
+        return {"idx": t, "step": self._step, "date": self.df.index.values[t],
+                "position_index": position_index, "position": self._position,
+                "real_position": real_position,
+                "data": dict(zip(self._info_columns, self._info_array[t])),
+                "portfolio_valuation": valuation,
+                "portfolio_distribution": self._distribution(), "reward": 0}
+
     def _get_price(self, delta=0):
         return self._price_array[self._idx + delta]
 
@@ -159,13 +169,9 @@ class TradingEnv(_EnvBase):
                           inject_position_index=[self.positions.index(position)])
         self._sync_state()
         self.historical_info = History(max_size=len(self.df))
-        self.historical_info.set(
-            idx=self._idx, step=self._step, date=self.df.index.values[self._idx],
-            position_index=self.positions.index(self._position), position=self._position,
-            real_position=self._position,
-            data=dict(zip(self._info_columns, self._info_array[self._idx])),
-            portfolio_valuation=self.portfolio_initial_value,
-            portfolio_distribution=self._distribution(), reward=0)
+        self.historical_info.set(**self._row(self.positions.index(self._position),
+                                             real_position=self._position,
+                                             valuation=self.portfolio_initial_value))
         return self._obs(), self.historical_info[0]
 
     def render(self):
@@ -192,13 +198,8 @@ class TradingEnv(_EnvBase):
         self._sync_state()
         done = bool(self._batch.read_output("terminated")[0])
         truncated = bool(self._batch.read_output("truncated")[0])
-        self.historical_info.add(
-            idx=self._idx, step=self._step, date=self.df.index.values[self._idx],
-            position_index=position_index, position=self._position,
-            real_position=self._real_position,
-            data=dict(zip(self._info_columns, self._info_array[self._idx])),
-            portfolio_valuation=self._portfolio_value,
-            portfolio_distribution=self._distribution(), reward=0)
+        self.historical_info.add(**self._row(position_index, real_position=self._real_position,
+                                             valuation=self._portfolio_value))
         if not done:
             reward = (self.reward_function(self.historical_info) if self._host_reward
                       else np.float64(self._batch.read_output("reward64")[0]))
@@ -215,35 +216,33 @@ class TradingEnv(_EnvBase):
 
     def calculate_metrics(self):
         h = self.historical_info
-        self.results_metrics = {
-            "Market Return": f"{100 * (h['data_close', -1] / h['data_close', 0] - 1):5.2f}%",
-            "Portfolio Return":
-                f"{100 * (h['portfolio_valuation', -1] / h['portfolio_valuation', 0] - 1):5.2f}%",
-        }
-        for metric in self.log_metrics:
-            self.results_metrics[metric["name"]] = metric["function"](h)
+
+        def pct(column):  # first-to-last change of a History column, the reference's format
+            return f"{100 * (h[column, -1] / h[column, 0] - 1):5.2f}%"
+        results = {"Market Return": pct("data_close"),
+                   "Portfolio Return": pct("portfolio_valuation")}
+        results.update((m["name"], m["function"](h)) for m in self.log_metrics)
+        self.results_metrics = results
 
     def get_metrics(self):
         return self.results_metrics
 
     def log(self):
-        if self.verbose > 0:
-            print("".join(f"{k} : {v}   |   " for k, v in self.results_metrics.items()))
+        if self.verbose <= 0:
+            return
+        print("".join(f"{name} : {value}   |   " for name, value in self.results_metrics.items()))
 
     def save_for_render(self, dir="render_logs"):
         """Pickle `df` joined with the episode History (:296-307), for the renderer."""
         import pandas as pd
-        assert all(c in self.df for c in ("open", "high", "low", "close")), (
+        missing = [c for c in ("open", "high", "low", "close") if c not in self.df]
+        assert not missing, (
             "Your DataFrame needs to contain columns : open, high, low, close to render !")
-        cols = [c for c in self.historical_info.columns
-                if c not in {f"date_{col}" for col in self._info_columns}]
-        history_df = pd.DataFrame(self.historical_info[cols], columns=cols)
-        history_df.set_index("date", inplace=True)
-        history_df.sort_index(inplace=True)
-        render_df = self.df.join(history_df, how="inner")
+        h = self.historical_info
+        logged = pd.DataFrame({c: h[c] for c in h.columns}).set_index("date").sort_index()
         os.makedirs(dir, exist_ok=True)
         stamp = datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S")
-        render_df.to_pickle(f"{dir}/{self.name}_{stamp}.pkl")
+        self.df.join(logged, how="inner").to_pickle(os.path.join(dir, f"{self.name}_{stamp}.pkl"))
 
     def close(self):
         if self._batch is not None:
@@ -268,14 +267,17 @@ class MultiDatasetTradingEnv(TradingEnv):
         super().__init__(self.next_dataset(), *args, **kwargs)
 
     def next_dataset(self):
+        """Uniform draw among the least-used dataset files (:380-391); same single
+        `np.random.randint(n)` call as the reference, so the global RNG stays in step."""
         import pandas as pd
         self._episodes_on_this_dataset = 0
-        candidates = np.where(self.dataset_nb_uses == self.dataset_nb_uses.min())[0]
-        dataset_idx = candidates[np.random.randint(candidates.size)]
-        self.dataset_nb_uses[dataset_idx] += 1
-        path = self.dataset_pathes[dataset_idx]
-        self.name = Path(path).name
-        return self.preprocess(pd.read_pickle(path))  # the user's own dataset files
+        uses = self.dataset_nb_uses
+        least_used = np.flatnonzero(uses == uses.min())
+        chosen = int(least_used[np.random.randint(least_used.size)])
+        uses[chosen] += 1
+        self.name = Path(self.dataset_pathes[chosen]).name
+        frame = pd.read_pickle(self.dataset_pathes[chosen])  # the user's own dataset files
+        return self.preprocess(frame)
 
     def reset(self, seed=None, options=None, **kwargs):
         self._episodes_on_this_dataset += 1
