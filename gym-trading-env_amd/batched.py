@@ -348,7 +348,9 @@ class BatchedTradingEnv:
                      (x.value for x in v)))
         flags, d["vector_bytes"] = divmod(d["vector_bytes"], 1000)
         d["phase_a"] = "cooperative" if flags & 1 else "per-wave"
-        d["dyn_columns"] = ("global", "lds-raw-rings", "lds-resolved")[flags >> 1]
+        d["dyn_columns"] = ("global", "lds-raw-rings", "lds-resolved")[(flags >> 1) & 3]
+        d["structure"] = ("overlapped (waves 1-3 copy predicted windows during phase A)"
+                          if flags & 8 else "classic (phase A, barrier, gather)")
         return d
 
     def timer_start(self):

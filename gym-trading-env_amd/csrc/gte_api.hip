@@ -23,6 +23,8 @@ hipError_t launch_step(const Params& p, int vec, bool nt, bool coop, int stage, 
 hipError_t launch_reset(const Params& p, int vec, bool nt, bool coop, int stage, int blocks,
                         int threads, hipStream_t stream);
 size_t lds_bytes(const Params& p, int stage);
+size_t lds_bytes_overlap(const Params& p);
+hipError_t launch_step_overlap(const Params& p, int vec, bool nt, hipStream_t stream);
 struct StateSoA {
   int32_t *idx, *step, *pos, *dsi, *start, *episode, *needs_reset;
   double *asset, *fiat, *ia, *ifi, *pv, *realpos;
@@ -83,6 +85,7 @@ struct gte_env {
   int vec = 1, blocks = 0, threads = 256;
   bool coop = false;       // wave 0 of a workgroup runs phase A for the whole workgroup
   int stage = 0;           // dynamic columns: 0 global, 1 raw rings in LDS, 2 resolved in LDS
+  bool overlap = false;    // gte_step uses the overlapped kernel (gte_step_overlap_kernel)
   int32_t* term_base = nullptr;  // the two-slot terminal counter in use (owned or bound)
   int term_slot = 0;       // slot the last launch added to
   // L2-affinity processing order (gte_kernels.hip, "L2-affinity permutation")
@@ -285,6 +288,16 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   const int64_t waves = ((int64_t)p.N + epw - 1) / epw;
   E->threads = 256;
   E->blocks = (int)((waves + 3) / 4);
+  // overlapped step kernel: windowed, W-deep rings, 64 envs per workgroup.  gte_reset keeps
+  // the classic kernel (a reset has no prediction to start from).
+  if (!(cfg->kernel_variant & 4) && !p.persist && p.W >= 2 && E->stage == 1 &&
+      (cfg->envs_per_wave == 0 || cfg->envs_per_wave == 16) && gte::lds_bytes_overlap(p) <= 48 * 1024) {
+    E->overlap = true;
+    epw = 16;
+    p.epw = 16;
+    E->coop = true;
+    E->blocks = (p.N + 63) / 64;
+  }
   // L2-affinity order: only worth it when every XCD gets several workgroups and the
   // windows are big enough to be bandwidth-bound
   {
@@ -488,8 +501,11 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
   E->term_slot ^= 1;
   p.term_count = E->term_base + E->term_slot;
   p.term_count_next = E->term_base + (E->term_slot ^ 1);
-  HIPCHK(gte::launch_step(p, E->vec, E->cfg.nontemporal_obs != 0, E->coop, E->stage, E->blocks,
-                          E->threads, E->stream));
+  if (E->overlap)
+    HIPCHK(gte::launch_step_overlap(p, E->vec, E->cfg.nontemporal_obs != 0, E->stream));
+  else
+    HIPCHK(gte::launch_step(p, E->vec, E->cfg.nontemporal_obs != 0, E->coop, E->stage, E->blocks,
+                            E->threads, E->stream));
   return GTE_OK;
 }
 
@@ -627,7 +643,7 @@ int gte_get_launch_info(gte_env* E, int32_t* envs_per_wave, int32_t* threads_per
   if (envs_per_wave) *envs_per_wave = E->p.epw;
   if (threads_per_block) *threads_per_block = E->threads;
   if (n_blocks) *n_blocks = E->blocks;
-  if (vector_bytes) *vector_bytes = E->vec * 4 + 1000 * ((E->coop ? 1 : 0) + 2 * E->stage);
+  if (vector_bytes) *vector_bytes = E->vec * 4 + 1000 * ((E->coop ? 1 : 0) + 2 * E->stage + (E->overlap ? 8 : 0));
   return GTE_OK;
 }
 

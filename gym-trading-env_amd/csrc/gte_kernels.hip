@@ -200,11 +200,43 @@ __device__ inline void make_job(const Params& p, int e, const EnvRegs& s, bool f
   job.flags = 1 | ((fresh && p.persist) ? 2 : 0);
 }
 
+// The window a step will most likely produce, known from the OLD state alone (before
+// the fp64 state machine has run): the env advances one row (or stays, if it is a
+// frozen finished env).  Envs that are about to be reset have no prediction.  Used by
+// the overlapped step kernel.  Non-persist layout only (W-deep ring).
+struct Prediction {
+  const float* src;
+  int32_t slot0, n_zero;
+  bool ok;
+};
+
+__device__ inline Prediction predict_job(const Params& p, int32_t idx, int32_t dsi,
+                                         int32_t start, int32_t needs_reset) {
+  Prediction q;
+  q.ok = true;
+  int32_t idx_new = idx + 1;
+  if (needs_reset) {
+    if (p.autoreset == GTE_AUTORESET_NEXT_STEP) q.ok = false;   // will be reset
+    else if (idx >= (int32_t)p.ds[dsi].T - 1) idx_new = idx;   // frozen
+  }
+  const int32_t first = idx_new - p.W + 1;
+  q.src = p.ds[dsi].feat + (int64_t)first * p.Fobs;
+  q.slot0 = (idx_new + 1) % p.W;
+  const int32_t nz = start - first;
+  q.n_zero = nz < 0 ? 0 : (nz > p.W - 1 ? p.W - 1 : nz);
+  return q;
+}
+
 // ---------------------------------------------------------------------------
 // phase A
 
+struct OldState {  // what phase A started from (for the prediction check)
+  int32_t idx, dsi, start, needs_reset;
+};
+
 template <int MODE>
-__device__ inline void phase_a(const Params& p, int e, bool active, int lane, ObsJob& job) {
+__device__ inline void phase_a(const Params& p, int e, bool active, int lane, ObsJob& job,
+                               OldState* old = nullptr) {
   job.src = nullptr; job.slot0 = 0; job.n_zero = 0; job.idx = 0; job.flags = 0;
 #pragma unroll
   for (int i = 0; i < GTE_MAX_DYN; ++i) job.cur[i] = 0.0f;
@@ -232,6 +264,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
   if (active) {
     EnvRegs s;
     load_state(p, e, s);
+    if (old) { old->idx = s.idx; old->dsi = s.dsi; old->start = s.start; old->needs_reset = s.needs_reset; }
     int32_t action = p.actions[e];
     // positions[position_index] raises IndexError in the reference (:234); a device-side
     // action cannot raise, so an out-of-range index is treated as None (hold), never read
@@ -323,46 +356,57 @@ __device__ inline void store_out(T* dst, const T& v) {
 
 // LDS image of a workgroup: the jobs phase A hands to phase B (one per env of the
 // workgroup) and, when STAGE, the dynamic-column values of every window row.
+// One 16-byte job record per env of the workgroup: a single ds_read_b128 per vector in
+// the copy loop (five separate LDS reads measurably throttled the loop).
+struct alignas(16) JobRec {
+  uint64_t src;   // first row of the window in the feature table
+  int32_t env;    // env id processed in this slot (perm[slot], or the slot itself); -1 = none
+  uint32_t meta;  // bit0 copy the window, bit1 zero the env's dynamic store,
+                  // bits 2..16 n_zero, bits 17..31 slot0  (W < 32768)
+};
+__device__ inline uint32_t pack_meta(int flags, int n_zero, int slot0) {
+  return (uint32_t)(flags & 3) | ((uint32_t)n_zero << 2) | ((uint32_t)slot0 << 17);
+}
+__device__ inline int meta_flags(uint32_t m) { return (int)(m & 3u); }
+__device__ inline int meta_n_zero(uint32_t m) { return (int)((m >> 2) & 0x7FFFu); }
+__device__ inline int meta_slot0(uint32_t m) { return (int)(m >> 17); }
+
+// LDS image of a workgroup: the jobs phase A hands to phase B (one per env of the
+// workgroup) and, when staged, the dynamic-column values of every window row.
 struct WgLds {
-  int32_t* env;     // [EPB] env id processed in this slot (perm[slot], or slot itself)
-  uint64_t* src;    // [EPB] first row of the window in the feature table
-  int32_t* flags;   // [EPB] bit0 copy the window, bit1 zero the env's dynamic store
-  int32_t* idx;     // [EPB]
-  int32_t* slot0;   // [EPB]
-  int32_t* n_zero;  // [EPB]
-  float* cur;       // [EPB][GTE_MAX_DYN]
-  float* staged;    // [EPB][W][nd]  (STAGE only)
+  JobRec* job;      // [EPB]
+  int32_t* idx;     // [EPB] current row (persist mode's zero-fill needs it)
+  float* cur;       // [EPB][GTE_MAX_DYN] dynamic features of the current row
+  float* staged;    // [EPB][W][nd]
 };
 
 __device__ inline WgLds carve_lds(unsigned char* base, int EPB) {
   WgLds L;
-  L.src = (uint64_t*)base;                 base += 8 * EPB;
+  L.job = (JobRec*)base;                   base += 16 * EPB;
   L.cur = (float*)base;                    base += 4 * GTE_MAX_DYN * EPB;
-  L.flags = (int32_t*)base;                base += 4 * EPB;
   L.idx = (int32_t*)base;                  base += 4 * EPB;
-  L.slot0 = (int32_t*)base;                base += 4 * EPB;
-  L.n_zero = (int32_t*)base;               base += 4 * EPB;
-  L.env = (int32_t*)base;                  base += 4 * EPB;
   L.staged = (float*)base;
   return L;
 }
 
+// phase A's lane publishes its env's job (the env id was written at kernel start)
 __device__ inline void publish_job(const WgLds& L, int slot, const ObsJob& job) {
-  L.src[slot] = (uint64_t)job.src;
-  L.flags[slot] = job.flags;
+  L.job[slot].src = (uint64_t)job.src;
+  L.job[slot].meta = pack_meta(job.flags, job.n_zero, job.slot0);
   L.idx[slot] = job.idx;
-  L.slot0[slot] = job.slot0;
-  L.n_zero[slot] = job.n_zero;
 #pragma unroll
   for (int i = 0; i < GTE_MAX_DYN; ++i) L.cur[slot * GTE_MAX_DYN + i] = job.cur[i];
 }
 
-// value of dynamic feature i in window row w of the env in LDS slot `s`
+// value of dynamic feature i in window row w of the env in LDS slot `s` (generic form:
+// reads the env's store in global memory; used by the persist-mode staging and when
+// nothing is staged)
 __device__ inline float dyn_value(const Params& p, const WgLds& L, int s, const float* ring_e,
                                   int w, int i) {
   if (w == p.W - 1) return L.cur[s * GTE_MAX_DYN + i];  // current row: from phase A
-  if (w < L.n_zero[s]) return 0.0f;                      // never written: reads as zero
-  int32_t slot = L.slot0[s] + w;
+  const uint32_t m = L.job[s].meta;
+  if (w < meta_n_zero(m)) return 0.0f;                   // never written: reads as zero
+  int32_t slot = meta_slot0(m) + w;
   if (!p.persist && slot >= p.W) slot -= p.W;
   return ring_e[(int64_t)slot * p.nd + i];
 }
@@ -380,7 +424,7 @@ __device__ inline void stage_dynamic(const Params& p, const WgLds& L, int s_firs
     const uint32_t w = r / (uint32_t)p.nd;
     const int i = (int)(r - w * (uint32_t)p.nd);
     const int s = s_first + (int)el;
-    const float* ring_e = p.ring + (int64_t)L.env[s] * p.depth * p.nd;
+    const float* ring_e = p.ring + (int64_t)L.job[s].env * p.depth * p.nd;
     L.staged[(uint32_t)s * WND + r] = dyn_value(p, L, s, ring_e, (int)w, i);
   }
 }
@@ -400,40 +444,43 @@ __device__ inline void stage_raw_rings(const Params& p, const WgLds& L, int s_fi
   for (uint32_t k = (uint32_t)lane; k < total; k += 64u) {
     const uint32_t el = fastdiv40(k, wnd_magic);
     const uint32_t r = k - el * WND;
-    dst[k] = p.ring[(int64_t)L.env[s_first + (int)el] * WND + r];  // depth == W here
+    dst[k] = p.ring[(int64_t)L.job[s_first + (int)el].env * WND + r];  // depth == W here
   }
 }
 
-__device__ inline float dyn_value_raw(const Params& p, const WgLds& L, int s, int w, int i) {
-  if (w == p.W - 1) return L.cur[s * GTE_MAX_DYN + i];
-  if (w < L.n_zero[s]) return 0.0f;
-  int32_t slot = L.slot0[s] + w;
-  if (slot >= p.W) slot -= p.W;
-  return L.staged[(s * p.W + slot) * p.nd + i];
-}
-
 // Overwrite the dynamic columns that vector `v` (columns col .. col+VEC-1 of window
-// row w of the env in LDS slot s) covers.  Every index into v is a compile-time
-// constant after unrolling: a run-time index would put v in scratch memory (measured:
-// one scratch store per observation store, 2x WRITE_SIZE).
+// row w of the env in LDS slot s, job meta m) covers.  Straight-line code under ONE
+// branch: nested divergent branches here cost ~250 instructions and a dozen
+// s_waitcnt per vector.  Every index into v is a compile-time constant after
+// unrolling: a run-time index would put v in scratch memory (measured: one scratch
+// store per observation store, 2x WRITE_SIZE).
 template <int VEC, int STAGE, typename vec_t>
-__device__ inline void patch_dynamic(const Params& p, const WgLds& L, vec_t& v, int s,
+__device__ inline void patch_dynamic(const Params& p, const WgLds& L, vec_t& v, int s, uint32_t m,
                                      const float* ring_e, int w, int col) {
   if (col + VEC <= p.Fs || (p.debug & 2)) return;  // all static columns
+  const bool is_cur = (w == p.W - 1);
+  int32_t slot = meta_slot0(m) + w;
+  if (STAGE == STAGE_RAW) slot -= (slot >= p.W) ? p.W : 0;
+  const bool zero = !is_cur && w < meta_n_zero(m);
 #pragma unroll
   for (int i = 0; i < GTE_MAX_DYN; ++i) {
-    if (i < p.nd) {
-      const int c = p.Fs + i - col;  // component of v that holds dynamic feature i
-      if (c >= 0 && c < VEC) {
-        const float x = STAGE == STAGE_LATE  ? L.staged[(s * p.W + w) * p.nd + i]
-                        : STAGE == STAGE_RAW ? dyn_value_raw(p, L, s, w, i)
-                                             : dyn_value(p, L, s, ring_e, w, i);
-        if (VEC == 1) {
-          v = x;
-        } else {
+    if (i < p.nd) {  // wave-uniform
+      const int c = p.Fs + i - col;  // component of v holding dynamic feature i (if 0..VEC-1)
+      float x;
+      if (STAGE == STAGE_RAW) {        // raw rings in LDS: pick the address, one LDS read
+        const float* a = is_cur ? &L.cur[s * GTE_MAX_DYN + i] : &L.staged[(s * p.W + slot) * p.nd + i];
+        x = *a;
+        x = zero ? 0.0f : x;
+      } else if (STAGE == STAGE_LATE) {  // already resolved per window row
+        x = L.staged[(s * p.W + w) * p.nd + i];
+      } else {
+        x = dyn_value(p, L, s, ring_e, w, i);
+      }
+      if (VEC == 1) {
+        if (c == 0) v = x;
+      } else {
 #pragma unroll
-          for (int k = 0; k < VEC; ++k) v[k] = (c == k) ? x : v[k];
-        }
+        for (int k = 0; k < VEC; ++k) v[k] = (c == k) ? x : v[k];
       }
     }
   }
@@ -455,7 +502,8 @@ __device__ inline void phase_b(const Params& p, const WgLds& L, int s_first,
 
   for (uint32_t k0 = 0; k0 < total; k0 += 64u * U) {
     vec_t v[U];
-    uint32_t jj[U], ee[U];
+    uint32_t jj[U], ee[U], mm[U];
+    int32_t env[U];
     bool ok[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -464,9 +512,11 @@ __device__ inline void phase_b(const Params& p, const WgLds& L, int s_first,
       const uint32_t kk = in ? k : 0u;
       ee[u] = fastdiv40(kk, vpe_magic);
       jj[u] = kk - ee[u] * VPE;
-      const int s = s_first + (int)ee[u];
-      ok[u] = in && (L.flags[s] & 1);
-      if (ok[u]) v[u] = *(const vec_t*)((const float*)L.src[s] + (int64_t)jj[u] * VEC);
+      const JobRec j = L.job[s_first + (int)ee[u]];  // one ds_read_b128
+      mm[u] = j.meta;
+      env[u] = j.env;
+      ok[u] = in && (j.meta & 1u);
+      if (ok[u]) v[u] = *(const vec_t*)((const float*)j.src + (int64_t)jj[u] * VEC);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -474,10 +524,9 @@ __device__ inline void phase_b(const Params& p, const WgLds& L, int s_first,
       const uint32_t w = fastdiv40(jj[u], fv_magic);
       const int col = (int)(jj[u] - w * FV) * VEC;
       const int s = s_first + (int)ee[u];
-      const int64_t env = L.env[s];
-      const float* ring_e = p.ring + env * p.depth * p.nd;
-      patch_dynamic<VEC, STAGE>(p, L, v[u], s, ring_e, (int)w, col);
-      store_out<NT>((vec_t*)(p.obs + env * V + (int64_t)jj[u] * VEC), v[u]);
+      const float* ring_e = p.ring + (int64_t)env[u] * p.depth * p.nd;
+      patch_dynamic<VEC, STAGE>(p, L, v[u], s, mm[u], ring_e, (int)w, col);
+      store_out<NT>((vec_t*)(p.obs + (int64_t)env[u] * V + (int64_t)jj[u] * VEC), v[u]);
     }
   }
 }
@@ -488,9 +537,9 @@ __device__ inline void zero_fresh_stores(const Params& p, const WgLds& L,
                                          int s_first, int n_env, int lane) {
   for (int el = 0; el < n_env; ++el) {
     const int s = s_first + el;
-    if (!(L.flags[s] & 2)) continue;
+    if (!(L.job[s].meta & 2u)) continue;
     const int idx = L.idx[s];
-    float* ring_e = p.ring + (int64_t)L.env[s] * p.depth * p.nd;
+    float* ring_e = p.ring + (int64_t)L.job[s].env * p.depth * p.nd;
     const int64_t n = p.depth * p.nd;
     const int64_t keep_lo = (int64_t)idx * p.nd, keep_hi = keep_lo + p.nd;
     for (int64_t k = lane; k < n; k += 64)
@@ -524,7 +573,7 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
   // permutation (envs reading the same table region share an XCD, see gte_api.hip)
   if (lane < p.epw) {
     const int slot = wg_first + s_first + lane;
-    L.env[s_first + lane] = (lane < n_env) ? (p.perm ? p.perm[slot] : slot) : -1;
+    L.job[s_first + lane].env = (lane < n_env) ? (p.perm ? p.perm[slot] : slot) : -1;
   }
   if (STAGE == STAGE_RAW && n_env > 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -557,6 +606,223 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   phase_b<VEC, NT, STAGE, 4>(p, L, s_first, n_env, lane, vpe_magic, fv_magic);
+}
+
+// ---------------------------------------------------------------------------
+// Overlapped step kernel (default for windowed, non-persist shapes).
+//
+// Phase A is a ~10 us latency chain (record gather, price gathers, fp64 divisions)
+// during which the classic kernel moves no observation bytes.  Almost all of a window
+// does not depend on it: a stepping env advances one row, so rows 0..W-2 of its new
+// window (static columns AND the dynamic values of earlier rows, which sit in the
+// env's ring) are known from the OLD state.  Workgroup = 4 waves = 64 envs:
+//   waves 1..3  predict the windows of their 16 envs from the old state and copy
+//               rows 0..W-2 immediately;
+//   wave 0      runs phase A for all 64 envs (one per lane), publishes the real jobs
+//               and lists the envs whose whole window must (still) be copied: its own
+//               16 envs and every env whose real job differs from the prediction
+//               (resets);
+//   barrier, then all 4 waves share (A) the listed envs' whole windows and (B) the
+//               last row of every other env (it needs phase A's dynamic values).
+// A mispredicted env's early rows are simply rewritten in (A); __syncthreads drains
+// every wave's stores first.
+struct OverlapLds {
+  JobRec* job;      // [64] real jobs (wave 0)
+  JobRec* pjob;     // [64] predicted jobs (waves 1..3, slots 16..63)
+  float* cur;       // [64][GTE_MAX_DYN]
+  int32_t* full;    // [64] 1 = whole window copied after the barrier
+  int32_t* list;    // [64] compacted slots with full == 1
+  int32_t* n_full;  // [1]
+  float* staged;    // [64][W][nd] raw rings
+};
+
+__device__ inline OverlapLds carve_overlap(unsigned char* base) {
+  OverlapLds L;
+  L.job = (JobRec*)base;   base += 16 * 64;
+  L.pjob = (JobRec*)base;  base += 16 * 64;
+  L.cur = (float*)base;    base += 4 * GTE_MAX_DYN * 64;
+  L.full = (int32_t*)base; base += 4 * 64;
+  L.list = (int32_t*)base; base += 4 * 64;
+  L.n_full = (int32_t*)base; base += 16;
+  L.staged = (float*)base;
+  return L;
+}
+
+size_t lds_bytes_overlap(const Params& p) {
+  return 64 * (16 + 16 + 4 * GTE_MAX_DYN + 4 + 4) + 16 + (size_t)64 * p.W * (p.nd ? p.nd : 1) * 4;
+}
+
+// One flat gather over `n_items` envs x `per_env` vectors (vectors vec0 .. vec0+per_env-1
+// of each window).  Item el is LDS slot list[el] (or s_base + el).  The calling wave
+// takes chunks k_begin, k_begin + k_stride, ... of 64*U vectors.
+//   EARLY: jobs are predictions and only rows < W-1 are touched, so the dynamic values
+//          come from the staged ring (or are zero); otherwise the row may be the current
+//          one, whose values are in L.cur.
+template <int VEC, bool NT, int U, bool EARLY>
+__device__ inline void copy_flat(const Params& p, const OverlapLds& L, const JobRec* jobs,
+                                 const int32_t* list, int s_base, const int32_t* skip_if,
+                                 uint32_t n_items, uint32_t per_env, uint64_t per_env_magic,
+                                 uint32_t vec0, uint32_t k_begin, uint32_t k_stride, int lane,
+                                 uint64_t fv_magic) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  const uint32_t V = (uint32_t)(p.W * p.Fobs);
+  const uint32_t FV = (uint32_t)p.Fobs / VEC;
+  const uint32_t total = n_items * per_env;
+  for (uint32_t k0 = k_begin; k0 < total; k0 += k_stride) {
+    vec_t v[U];
+    uint32_t jj[U], mm[U];
+    int32_t env[U], ss[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t k = k0 + (uint32_t)u * 64u + (uint32_t)lane;
+      const bool in = k < total;
+      const uint32_t kk = in ? k : 0u;
+      const uint32_t el = fastdiv40(kk, per_env_magic);
+      jj[u] = vec0 + (kk - el * per_env);
+      const int s = list ? list[el] : s_base + (int)el;
+      const JobRec j = jobs[s];  // one ds_read_b128
+      ss[u] = s;
+      mm[u] = j.meta;
+      env[u] = j.env;
+      ok[u] = in && (j.meta & 1u) && !(skip_if && skip_if[s]);
+      if (ok[u]) v[u] = *(const vec_t*)((const float*)j.src + (int64_t)jj[u] * VEC);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      const uint32_t w = fastdiv40(jj[u], fv_magic);
+      const int col = (int)(jj[u] - w * FV) * VEC;
+      if (col + VEC > p.Fs && !(p.debug & 2)) {  // this vector holds dynamic columns
+        const int s = ss[u];
+        const bool is_cur = !EARLY && ((int)w == p.W - 1);
+        int32_t slot = meta_slot0(mm[u]) + (int32_t)w;
+        slot -= (slot >= p.W) ? p.W : 0;
+        const bool zero = !is_cur && (int)w < meta_n_zero(mm[u]);
+#pragma unroll
+        for (int i = 0; i < GTE_MAX_DYN; ++i) {
+          if (i < p.nd) {  // wave-uniform
+            const int c = p.Fs + i - col;
+            const float* a = is_cur ? &L.cur[s * GTE_MAX_DYN + i]
+                                    : &L.staged[(s * p.W + slot) * p.nd + i];
+            float x = *a;
+            x = zero ? 0.0f : x;
+            if (VEC == 1) {
+              if (c == 0) v[u] = x;
+            } else {
+#pragma unroll
+              for (int kq = 0; kq < VEC; ++kq) v[u][kq] = (c == kq) ? x : v[u][kq];
+            }
+          }
+        }
+      }
+      store_out<NT>((vec_t*)(p.obs + (int64_t)env[u] * V + (int64_t)jj[u] * VEC), v[u]);
+    }
+  }
+}
+
+template <int VEC, bool NT, int U>
+__global__ __launch_bounds__(256) void gte_step_overlap_kernel(const Params p, const uint64_t fv_magic,
+                                                               const uint64_t wnd_magic,
+                                                               const uint64_t early_magic,
+                                                               const uint64_t vpe_magic) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gte_smem[];
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0) p.term_count_next[0] = 0;
+  const int wg_first = blockIdx.x * 64;
+  const int n_wg = min(64, p.N - wg_first);  // grid = ceil(N / 64)
+  const OverlapLds L = carve_overlap(gte_smem);
+  const uint32_t FV = (uint32_t)p.Fobs / VEC;
+  const uint32_t VPE = (uint32_t)(p.W * p.Fobs) / VEC;
+  // 16 slots per wave.  Wave 0's envs can only be copied after phase A; giving it fewer
+  // (8 / 4 / 1 of the 64) measured no better (46.8 / 46.9 / 48.2 us vs 46.3 us) and a
+  // run-time split cost 3 us against this compile-time one (profiles/r01_tune_overlap.log)
+  const int s_first = wib * 16;
+  const int n_env = max(0, min(16, n_wg - s_first));
+
+  // env ids of this wave's slots (identity or the L2-affinity permutation), raw rings
+  if (lane < 16) {
+    const int slot = wg_first + s_first + lane;
+    const int env = (lane < n_env) ? (p.perm ? p.perm[slot] : slot) : -1;
+    L.job[s_first + lane].env = env;
+    L.pjob[s_first + lane].env = env;
+    L.pjob[s_first + lane].meta = 0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (p.nd > 0 && n_env > 0) {
+    const uint32_t WND = (uint32_t)(p.W * p.nd);
+    const uint32_t total = (uint32_t)n_env * WND;
+    float* dst = L.staged + (uint32_t)s_first * WND;
+    for (uint32_t k = (uint32_t)lane; k < total; k += 64u) {
+      const uint32_t el = fastdiv40(k, wnd_magic);
+      dst[k] = p.ring[(int64_t)L.job[s_first + (int)el].env * WND + (k - el * WND)];
+    }
+  }
+
+  if (wib == 0) {
+    // ---------------- wave 0: phase A for the whole workgroup
+    const int s = lane;
+    const bool active = s < n_wg;
+    const int e = active ? (p.perm ? p.perm[wg_first + s] : wg_first + s) : 0;
+    ObsJob job;
+    OldState old = {0, 0, 0, 0};
+    phase_a<MODE_STEP>(p, e, active, lane, job, &old);
+    L.job[s].src = (uint64_t)job.src;
+    L.job[s].meta = pack_meta(job.flags, job.n_zero, job.slot0);
+#pragma unroll
+    for (int i = 0; i < GTE_MAX_DYN; ++i) L.cur[s * GTE_MAX_DYN + i] = job.cur[i];
+    bool full = false;
+    if (active && (job.flags & 1)) {
+      const Prediction q = predict_job(p, old.idx, old.dsi, old.start, old.needs_reset);
+      full = s < 16 || !q.ok || q.src != job.src || q.slot0 != job.slot0 || q.n_zero != job.n_zero;
+    }
+    L.full[s] = full ? 1 : 0;
+    const unsigned long long m = __ballot(full);
+    if (full) L.list[__popcll(m & ((1ull << lane) - 1ull))] = s;
+    if (lane == 0) L.n_full[0] = __popcll(m);
+  } else if (n_env > 0 && !(p.debug & 1)) {
+    // ---------------- waves 1..3: rows 0..W-2 of the predicted windows, right away
+    if (lane < n_env) {
+      const EnvRec* r = &p.rec[L.job[s_first + lane].env];
+      const Prediction q = predict_job(p, r->idx, r->dsi, r->start, r->needs_reset);
+      L.pjob[s_first + lane].src = (uint64_t)q.src;
+      L.pjob[s_first + lane].meta = pack_meta(q.ok ? 1 : 0, q.n_zero, q.slot0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    copy_flat<VEC, NT, U, true>(p, L, L.pjob, nullptr, s_first, nullptr, (uint32_t)n_env,
+                                VPE - FV, early_magic, 0u, 0u, 64u * U, lane, fv_magic);
+  }
+  __syncthreads();  // also drains every wave's stores (vmcnt(0)) before any rewrite below
+  if (p.debug & 1) return;
+  // (A) whole windows of the listed envs, (B) last rows of all the others; 4 waves interleave
+  copy_flat<VEC, NT, U, false>(p, L, L.job, L.list, 0, nullptr, (uint32_t)L.n_full[0], VPE, vpe_magic,
+                               0u, (uint32_t)wib * 64u * U, 4u * 64u * U, lane, fv_magic);
+  copy_flat<VEC, NT, U, false>(p, L, L.job, nullptr, 0, L.full, (uint32_t)n_wg, FV, fv_magic, VPE - FV,
+                               (uint32_t)wib * 64u * U, 4u * 64u * U, lane, fv_magic);
+}
+
+hipError_t launch_step_overlap(const Params& p, int vec, bool nt, hipStream_t stream) {
+  const uint32_t V = (uint32_t)(p.W * p.Fobs);
+  const uint32_t FV = (uint32_t)p.Fobs / vec, VPE = V / vec;
+  auto magic = [](uint32_t d) { return ((1ull << 40) + d - 1) / (d ? d : 1); };
+  const uint64_t fm = magic(FV), wm = magic((uint32_t)(p.W * (p.nd ? p.nd : 1))),
+                 em = magic(VPE - FV), vm = magic(VPE);
+  const int blocks = (p.N + 63) / 64;
+  const size_t smem = lds_bytes_overlap(p);
+#define GTE_O(VEC, NT, UU) \
+  hipLaunchKernelGGL((gte_step_overlap_kernel<VEC, NT, UU>), dim3(blocks), dim3(256), smem, stream, \
+                     p, fm, wm, em, vm)
+#define GTE_O_U(VEC, NT) GTE_O(VEC, NT, 4)  /* U = 8: 49.7 us, U = 2: 44.9 us, U = 4: 43.2 us */
+  if (vec == 4) { if (nt) GTE_O_U(4, true); else GTE_O_U(4, false); }
+  else          { if (nt) GTE_O_U(1, true); else GTE_O_U(1, false); }
+#undef GTE_O_U
+#undef GTE_O
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
@@ -670,7 +936,7 @@ static uint64_t magic40(uint32_t d) { return ((1ull << 40) + d - 1) / d; }
 
 size_t lds_bytes(const Params& p, int stage) {
   const size_t EPB = (size_t)p.epw * 4;
-  size_t b = EPB * (8 + 4 * GTE_MAX_DYN + 5 * 4);
+  size_t b = EPB * (16 + 4 * GTE_MAX_DYN + 4);
   if (stage) b += EPB * (size_t)p.W * (size_t)(p.nd ? p.nd : 1) * 4;
   return b;
 }

@@ -113,7 +113,8 @@ typedef struct gte_config {
   int32_t kernel_variant;   /* 0 = auto.  Bits for A/B timing of the kernel structure:
                                1 = every wave runs phase A for its own envs (no
                                cooperative phase A), 2 = no LDS staging of the
-                               dynamic columns (see csrc/gte_kernels.hip)       */
+                               dynamic columns, 4 = classic step kernel instead
+                               of the overlapped one (see csrc/gte_kernels.hip) */
   int32_t debug_flags;      /* timing ablations only (results become wrong):
                                1 = skip the observation gather, 2 = skip the
                                dynamic-column patch                               */
