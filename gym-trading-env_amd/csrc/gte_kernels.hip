@@ -354,6 +354,29 @@ __device__ inline void store_out(T* dst, const T& v) {
   else *dst = v;
 }
 
+// The window's source pointer travels through LDS as a 64-bit integer, which makes the
+// compiler forget that it points to global memory: it then emits flat_load, and flat
+// loads count on vmcnt AND lgkmcnt (every LDS read in the loop waits for them).  Cast
+// back to the global address space explicitly.
+template <typename T>
+__device__ inline T load_global(uint64_t base, int64_t index) {
+  typedef const T __attribute__((address_space(1))) * gptr_t;
+  return ((gptr_t)base)[index];
+}
+
+// Put nd dynamic values x[0..nd) into vector v, which is the LAST vector of a window row.
+// With 16-byte vectors F_obs % 4 == 0 and nd <= 4, so the dynamic columns are exactly the
+// last nd components of that vector: a wave-uniform switch, no per-component compares.
+__device__ inline void set_tail(float __attribute__((ext_vector_type(4))) & v, int nd,
+                                const float x[GTE_MAX_DYN]) {
+  switch (nd) {  // wave-uniform
+    case 1: v[3] = x[0]; break;
+    case 2: v[2] = x[0]; v[3] = x[1]; break;
+    case 3: v[1] = x[0]; v[2] = x[1]; v[3] = x[2]; break;
+    default: v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3]; break;
+  }
+}
+
 // LDS image of a workgroup: the jobs phase A hands to phase B (one per env of the
 // workgroup) and, when STAGE, the dynamic-column values of every window row.
 // One 16-byte job record per env of the workgroup: a single ds_read_b128 per vector in
@@ -462,27 +485,29 @@ __device__ inline void patch_dynamic(const Params& p, const WgLds& L, vec_t& v, 
   int32_t slot = meta_slot0(m) + w;
   if (STAGE == STAGE_RAW) slot -= (slot >= p.W) ? p.W : 0;
   const bool zero = !is_cur && w < meta_n_zero(m);
+  float x[GTE_MAX_DYN];
 #pragma unroll
   for (int i = 0; i < GTE_MAX_DYN; ++i) {
+    x[i] = 0.0f;
     if (i < p.nd) {  // wave-uniform
-      const int c = p.Fs + i - col;  // component of v holding dynamic feature i (if 0..VEC-1)
-      float x;
       if (STAGE == STAGE_RAW) {        // raw rings in LDS: pick the address, one LDS read
         const float* a = is_cur ? &L.cur[s * GTE_MAX_DYN + i] : &L.staged[(s * p.W + slot) * p.nd + i];
-        x = *a;
-        x = zero ? 0.0f : x;
+        x[i] = zero ? 0.0f : *a;
       } else if (STAGE == STAGE_LATE) {  // already resolved per window row
-        x = L.staged[(s * p.W + w) * p.nd + i];
+        x[i] = L.staged[(s * p.W + w) * p.nd + i];
       } else {
-        x = dyn_value(p, L, s, ring_e, w, i);
-      }
-      if (VEC == 1) {
-        if (c == 0) v = x;
-      } else {
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) v[k] = (c == k) ? x : v[k];
+        x[i] = dyn_value(p, L, s, ring_e, w, i);
       }
     }
+  }
+  if constexpr (VEC == 4) {
+    set_tail(v, p.nd, x);  // col + 4 > Fs  <=>  this is the row's last vector
+  } else {
+    const int i = col - p.Fs;  // VEC == 1: this element is dynamic feature i
+    float r = x[0];
+#pragma unroll
+    for (int k = 1; k < GTE_MAX_DYN; ++k) r = (i == k) ? x[k] : r;
+    v = r;
   }
 }
 
@@ -516,7 +541,7 @@ __device__ inline void phase_b(const Params& p, const WgLds& L, int s_first,
       mm[u] = j.meta;
       env[u] = j.env;
       ok[u] = in && (j.meta & 1u);
-      if (ok[u]) v[u] = *(const vec_t*)((const float*)j.src + (int64_t)jj[u] * VEC);
+      if (ok[u]) { if (p.debug & 8) v[u] = (vec_t)(float)jj[u]; else v[u] = load_global<vec_t>(j.src, (int64_t)jj[u]); }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -686,7 +711,7 @@ __device__ inline void copy_flat(const Params& p, const OverlapLds& L, const Job
       mm[u] = j.meta;
       env[u] = j.env;
       ok[u] = in && (j.meta & 1u) && !(skip_if && skip_if[s]);
-      if (ok[u]) v[u] = *(const vec_t*)((const float*)j.src + (int64_t)jj[u] * VEC);
+      if (ok[u]) { if (p.debug & 8) v[u] = (vec_t)(float)jj[u]; else v[u] = load_global<vec_t>(j.src, (int64_t)jj[u]); }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -699,21 +724,18 @@ __device__ inline void copy_flat(const Params& p, const OverlapLds& L, const Job
         int32_t slot = meta_slot0(mm[u]) + (int32_t)w;
         slot -= (slot >= p.W) ? p.W : 0;
         const bool zero = !is_cur && (int)w < meta_n_zero(mm[u]);
+        const float* a = is_cur ? &L.cur[s * GTE_MAX_DYN] : &L.staged[(s * p.W + slot) * p.nd];
+        float x[GTE_MAX_DYN];
 #pragma unroll
-        for (int i = 0; i < GTE_MAX_DYN; ++i) {
-          if (i < p.nd) {  // wave-uniform
-            const int c = p.Fs + i - col;
-            const float* a = is_cur ? &L.cur[s * GTE_MAX_DYN + i]
-                                    : &L.staged[(s * p.W + slot) * p.nd + i];
-            float x = *a;
-            x = zero ? 0.0f : x;
-            if (VEC == 1) {
-              if (c == 0) v[u] = x;
-            } else {
+        for (int i = 0; i < GTE_MAX_DYN; ++i) x[i] = (i < p.nd && !zero) ? a[i] : 0.0f;
+        if constexpr (VEC == 4) {
+          set_tail(v[u], p.nd, x);  // col + 4 > Fs  <=>  the row's last vector
+        } else {
+          const int i = col - p.Fs;
+          float r = x[0];
 #pragma unroll
-              for (int kq = 0; kq < VEC; ++kq) v[u][kq] = (c == kq) ? x : v[u][kq];
-            }
-          }
+          for (int kq = 1; kq < GTE_MAX_DYN; ++kq) r = (i == kq) ? x[kq] : r;
+          v[u] = r;
         }
       }
       store_out<NT>((vec_t*)(p.obs + (int64_t)env[u] * V + (int64_t)jj[u] * VEC), v[u]);

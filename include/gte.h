@@ -117,7 +117,8 @@ typedef struct gte_config {
                                of the overlapped one (see csrc/gte_kernels.hip) */
   int32_t debug_flags;      /* timing ablations only (results become wrong):
                                1 = skip the observation gather, 2 = skip the
-                               dynamic-column patch                               */
+                               dynamic-column patch, 8 = skip the window loads
+                               (stores only)                                      */
   int32_t affinity_period;  /* L2-affinity processing order: every this many steps the
                                envs are re-sorted by (dataset, table region) so that
                                each XCD's L2 serves one region (speed only; results

@@ -1,0 +1,56 @@
+"""`History` keeps the reference's access patterns (utils/history.py:3-76,
+docs/source/history.rst:18-46); the expectations below are the documented behaviour."""
+import numpy as np
+import pytest
+
+from gym_trading_env_amd.history import History
+
+
+def make():
+    h = History(max_size=100)
+    h.set(idx=0, step=0, position=1, data={"close": 10.0, "open": 9.0},
+          portfolio_distribution={"asset": 1.0, "fiat": 0.0}, levels=[1, 2], reward=0)
+    h.add(idx=1, step=1, position=0, data={"close": 11.0, "open": 10.0},
+          portfolio_distribution={"asset": 0.0, "fiat": 11.0}, levels=[3, 4], reward=0.5)
+    return h
+
+
+def test_columns_are_flattened_like_the_reference():
+    h = make()
+    assert h.columns == ["idx", "step", "position", "data_close", "data_open",
+                         "portfolio_distribution_asset", "portfolio_distribution_fiat",
+                         "levels_0", "levels_1", "reward"]
+    assert len(h) == 2 and h.width == 10
+
+
+def test_access_patterns():
+    h = make()
+    assert h["data_close", -1] == 11.0 and h["position", 0] == 1          # history[col, t]
+    assert h[-1]["reward"] == 0.5 and list(h[0]) == h.columns             # history[t] -> dict
+    np.testing.assert_array_equal(h["idx"], np.array([0, 1], dtype=object))  # history[col]
+    assert h["idx"].dtype == object
+    block = h[["position", "levels_1"]]                                    # history[[cols]]
+    assert block.shape == (2, 2) and block[1, 1] == 4
+    assert list(h["data_close", 0:2]) == [10.0, 11.0]
+    h["reward", -1] = 0.75                                                 # history[col, t] = v
+    assert h["reward", -1] == 0.75
+
+
+def test_errors_match_the_reference():
+    h = make()
+    with pytest.raises(ValueError, match="does not exist"):
+        h["nope", -1]
+    with pytest.raises(ValueError, match="does not exist"):
+        h[["idx", "nope"]]
+    with pytest.raises(ValueError, match="Make sur that your inputs match"):
+        h.add(idx=2, step=2)                                               # history.py:35-39
+    with pytest.raises(IndexError):
+        h["idx", 5]
+
+
+def test_full_history_overwrites_last_row():
+    h = History(max_size=2)
+    h.set(a=0)
+    h.add(a=1)
+    h.add(a=2)  # the reference's size stops at max_size and row max_size-1 is rewritten
+    assert len(h) == 2 and list(h["a"]) == [0, 2]
