@@ -52,10 +52,8 @@ class History:
         self._append(values)
 
     def _append(self, values):
-        if self.size >= self.height:  # the reference overwrites its last row when full
-            for c, v in zip(self.columns, values):
-                self._cols[c][-1] = v
-            return
+        if self.size >= self.height:  # the reference indexes row `size` of a `height`-row array
+            raise IndexError(f"index {self.size} is out of bounds for axis 0 with size {self.height}")
         for c, v in zip(self.columns, values):
             self._cols[c].append(v)
         self.size += 1

@@ -48,9 +48,10 @@ def test_errors_match_the_reference():
         h["idx", 5]
 
 
-def test_full_history_overwrites_last_row():
+def test_full_history_raises_like_the_reference():
     h = History(max_size=2)
     h.set(a=0)
     h.add(a=1)
-    h.add(a=2)  # the reference's size stops at max_size and row max_size-1 is rewritten
-    assert len(h) == 2 and list(h["a"]) == [0, 2]
+    with pytest.raises(IndexError):  # history_storage[size] with size == height (history.py:36)
+        h.add(a=2)
+    assert len(h) == 2 and list(h["a"]) == [0, 1]
