@@ -180,6 +180,29 @@ class BatchedTradingEnv:
         _abi.check(self._lib, self._lib.gte_get_outputs(self._h, C.byref(self._out)))
         self._was_reset = False
 
+    @classmethod
+    def from_dataset_dir(cls, dataset_dir: str, num_envs: int, *args,
+                         preprocess=lambda df: df, episodes_between_dataset_switch: int = 1,
+                         **kwargs):
+        """The batched `MultiDatasetTradingEnv` (environments.py:365-400): every file matched
+        by the glob `dataset_dir` is loaded (`pd.read_pickle`), passed through `preprocess`
+        and kept RESIDENT in HBM; each env moves to another dataset every
+        `episodes_between_dataset_switch` episodes, visiting all of them once per round in
+        random order (== uniform among the least-used ones, :383-388)."""
+        import glob
+        from pathlib import Path
+
+        import pandas as pd
+        paths = glob.glob(dataset_dir)
+        if len(paths) == 0:  # :376
+            raise FileNotFoundError(f"No dataset found with the path : {dataset_dir}")
+        frames = [preprocess(pd.read_pickle(p)) for p in paths]  # the user's own dataset files
+        env = cls(frames, num_envs, *args,
+                  episodes_between_dataset_switch=episodes_between_dataset_switch, **kwargs)
+        env.dataset_pathes = paths
+        env.dataset_names = [Path(p).name for p in paths]
+        return env
+
     # -- setup ---------------------------------------------------------------------
     def upload_dataset(self, d: int, s: staging.StagedDataset):
         """`_set_df` (environments.py:128-143): stage one dataset into HBM."""

@@ -171,3 +171,35 @@ def test_multidataset_dropin_replays_reference(tmp_path, monkeypatch, name, swit
     for e in range(2):
         env = _replay_env(g, e, mk, min(K, 200))
         env.close()
+
+
+def test_batched_from_dataset_dir(tmp_path, oracle_mod):
+    """Batch-level MultiDataset constructor: all pickles resident, per-env dataset switching;
+    checked against the oracle on the same seeds."""
+    from gym_trading_env_amd import BatchedTradingEnv
+    rng = np.random.default_rng(5)
+    sets = []
+    for d in range(6):
+        T = 120 + 7 * d
+        close = 100 * np.exp(np.cumsum(rng.normal(0, 1e-2, T)))
+        feat = rng.normal(0, 1, (T, 3)).astype(np.float32)
+        sets.append((feat, close))
+        make_df(feat, close).to_pickle(tmp_path / f"s{d}.pkl")
+    with pytest.raises(FileNotFoundError):
+        BatchedTradingEnv.from_dataset_dir(str(tmp_path / "none*.pkl"), 8)
+    calls = []
+    env = BatchedTradingEnv.from_dataset_dir(
+        str(tmp_path / "*.pkl"), 512, positions=[-1, 0, 1], windows=4, max_episode_duration=15,
+        preprocess=lambda df: (calls.append(len(df)) or df), output="numpy", seed=3)
+    assert len(calls) == 6 and len(env.datasets) == 6 and sorted(env.dataset_names) == [f"s{d}.pkl" for d in range(6)]
+    # the oracle gets the datasets in the env's (glob) order
+    staged = [(s.feat, s.close) for s in env.datasets]
+    ora = oracle_mod.OracleEnv(env.cfg, staged)
+    env.reset(); ora.reset()
+    for k in range(60):
+        a = rng.integers(-1, 3, 512).astype(np.int32)
+        env.step(a); ora.step(a)
+        np.testing.assert_array_equal(env.read_output("obs"), ora.obs)
+        np.testing.assert_array_equal(env.state("dataset_index"), ora.state()["dataset_index"])
+    assert len(np.unique(env.state("dataset_index"))) == 6   # envs spread over all datasets
+    env.close()
