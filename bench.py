@@ -149,7 +149,9 @@ def main():
     W = wl["windows"] or 1
     F_obs = wl["n_static"] + n_dyn
     D = wl["n_datasets"]
-    data = [synthetic_dataset(rank * D + d, wl["T"], wl["n_static"]) for d in range(D)]
+    # configs 2-4: ONE dataset replicated on every rank; config 5: symbols partitioned by rank
+    data = [synthetic_dataset((rank * D + d) if D > 1 else 0, wl["T"], wl["n_static"])
+            for d in range(D)]
     env = BatchedTradingEnv(data if D > 1 else data[0], num_envs=N, seed=20240607,
                             env_id_base=rank * N,
                             device=local_rank, output="torch", envs_per_wave=args.epw,

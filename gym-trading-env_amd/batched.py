@@ -273,6 +273,25 @@ class BatchedTradingEnv:
         n = int(self.read_output("term_count")[self._out.term_slot])
         return np.sort(self.read_output("term_ids")[:n])
 
+    def episode_metrics(self, env_ids=None) -> dict:
+        """Episode-end metrics of `calculate_metrics` (environments.py:279-286) for the envs
+        whose episode just ended (default: `terminal_ids()`), from the device state:
+        "Market Return" = close[idx] / close[start_idx] - 1 and "Portfolio Return" =
+        portfolio_valuation / initial value - 1, as float arrays plus the reference's
+        formatted strings.  Call it right after the terminal step (with next-step auto-reset
+        the state still belongs to the finished episode until the following step)."""
+        ids = self.terminal_ids() if env_ids is None else np.asarray(env_ids, dtype=np.int64)
+        ds, idx, start = (self.state(k)[ids] for k in ("dataset_index", "idx", "start_idx"))
+        pv = self.state("portfolio_valuation")[ids]
+        close_now = np.array([self.datasets[d].close[i] for d, i in zip(ds, idx)], dtype=np.float64)
+        close_0 = np.array([self.datasets[d].close[i] for d, i in zip(ds, start)], dtype=np.float64)
+        market = close_now / close_0 - 1 if len(ids) else np.zeros(0)
+        portfolio = pv / self.cfg.portfolio_initial_value - 1
+        return {"env_ids": ids, "market_return": market, "portfolio_return": portfolio,
+                "episode_length": self.state("step")[ids] + 1,
+                "Market Return": [f"{100 * m:5.2f}%" for m in market],
+                "Portfolio Return": [f"{100 * r:5.2f}%" for r in portfolio]}
+
     def _results(self):
         if self.output == "torch":
             t = self._t
