@@ -266,3 +266,31 @@ def test_injection_is_validated():
     info_keys = env.step(np.zeros(4, np.int32))[4]
     assert info_keys["_portfolio_valuation"].all() and "idx" in info_keys
     env.close()
+
+
+SHAPES = [
+    # (n_envs, n_static, windows, n_dyn kinds, positions, T, max_dur)
+    (1, 2, None, 2, [0, 1], 50, "max"),
+    (1, 30, 20, 2, [-1, 0, 1], 300, 40),
+    (63, 6, 1, 2, [-1, 0, 1], 80, 20),              # windows=1 is still a window: obs (1, F)
+    (65, 2, 2, 2, [0, 1], 60, 10),
+    (130, 8, 5, 0, [0, 0.5, 1], 90, 25),            # no dynamic features at all
+    (200, 3, 3, 1, [-1, 1], 70, "max"),             # one dynamic feature, F_obs = 4
+    (77, 510, 3, 2, [-1, 0, 1], 40, 12),            # wide rows: F_obs = 512
+    (40, 2, 512, 2, [-1, 0, 1], 1300, 60),          # long windows: 512 x 4
+    (300, 5, 64, 3, [-1, 0, 1], 400, 50),           # F_obs = 8, three dynamic features
+    (999, 12, 7, 4, list(np.linspace(-1, 2, 32)), 120, 30),  # 4 dynamic features, 32 positions
+    (5000, 29, 20, 2, [-1, 0, 1], 400, 35),         # F_obs = 31: 4-byte path at size
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: f"N{s[0]}_Fs{s[1]}_W{s[2]}_nd{s[3]}")
+@pytest.mark.parametrize("autoreset", ["next_step", "same_step"])
+def test_hip_vs_oracle_shape_sweep(oracle_mod, shape, autoreset):
+    n_envs, n_static, windows, nd, positions, T, max_dur = shape
+    kinds = ["last_position_taken", "real_position", "real_position", "last_position_taken"][:nd]
+    ds = [_synthetic(900 + n_static, T, n_static, sigma=2e-2, drift=-1e-3)]
+    _compare_with_oracle(oracle_mod, ds, n_envs=n_envs, steps=45, seed=17, check_every=3,
+                         windows=windows, positions=positions, dynamic_feature_functions=kinds,
+                         trading_fees=1e-3, borrow_interest_rate=1e-4,
+                         max_episode_duration=max_dur, autoreset=autoreset)
