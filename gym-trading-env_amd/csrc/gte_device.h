@@ -190,8 +190,8 @@ __device__ inline double reward_of(const Params& p, double pv, double pv_prev) {
   return lr;
 }
 
-// What phase A (one lane per env) hands to phase B (the whole wave copies the
-// observation windows).  Broadcast lane -> wave with v_readlane.
+// What phase A (one lane per env) hands to the gather (whole waves copy the
+// observation windows); published to LDS as a 16-byte JobRec + the current values.
 struct ObsJob {
   const float* src;   // first row of the window in the dataset's feature table
   int32_t idx;        // current row

@@ -2,26 +2,33 @@
 //
 // One launch advances every environment of the shard by one step
 // (TradingEnv.step, reference environments.py:233-272) or resets the masked
-// ones (TradingEnv.reset, :163-199).  Two phases per 256-thread workgroup (4
-// wavefronts, 4*EPW environments), handed over through LDS with one barrier:
+// ones (TradingEnv.reset, :163-199).  Workgroup = 256 threads = 4 wavefronts =
+// 64 environments at windowed shapes; two kinds of work:
 //
 //   phase A  one lane per environment: the scalar fp64 state machine
 //            (_take_action/_trade -> Portfolio.trade_to_position ->
-//            update_interest -> valorisation -> done/truncated -> reward),
-//            auto-reset with Philox or injected draws, and wave-level
-//            compaction of the terminal mask (__ballot + popcount prefix, one
-//            atomic per wave).  State is a struct of arrays, so the loads and
-//            stores of the active lanes are contiguous.
-//   phase B  the whole wave copies the EPW observation windows (_get_obs,
-//            :152-160): the window of env e is ONE contiguous block of
-//            W*F_obs floats of the row-major feature table, moved with
-//            16-byte loads/stores (1 KiB per wave instruction) and patched in
-//            flight with the dynamic columns, which the wave first stages in
-//            LDS with one coalesced pass over its envs' small dynamic stores
-//            (previous rows) and phase A's results (current row).
+//            limit-order fills -> update_interest -> valorisation ->
+//            done/truncated -> reward), auto-reset with Philox or injected
+//            draws, wave-level compaction of the terminal mask (__ballot +
+//            popcount prefix, one atomic per wave).  The per-env state is one
+//            128-byte record, reached through the L2-affinity permutation.
+//   gather   _get_obs (:152-160): the window of env e is ONE contiguous block of
+//            W*F_obs floats of the row-major feature table, moved with 16-byte
+//            loads / non-temporal stores (1 KiB per wave instruction) and patched
+//            in flight with the dynamic columns, which the wave first stages in
+//            LDS with one coalesced pass over its envs' small dynamic stores.
 //
-// The kernel is HBM-bound (no contraction, so no MFMA): >= 97 % of its bytes
-// are the window gather + observation store.  See DESIGN.md for the roofline.
+// Kernels:  gte_step_overlap_kernel  step, windowed shapes (default): waves 1-3
+//                                    gather predicted windows WHILE wave 0 runs
+//                                    phase A for the 64 envs;
+//           gte_kernel<MODE,...>     classic order (phase A, barrier, gather):
+//                                    resets, dyn_persist, windows=None, odd shapes;
+//           gte_affinity_*           counting sort of the envs by table region
+//                                    (processing order, speed only);
+//           gte_add_orders / gte_extract_state / gte_rewind_queue: small helpers.
+//
+// The path is HBM-bound (no contraction, so no MFMA): >= 97 % of its bytes are the
+// window gather + observation store.  See DESIGN.md for roofline and measurements.
 #include "gte_device.h"
 
 namespace gte {
