@@ -119,7 +119,8 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the workload's)")
     ap.add_argument("--epw", type=int, default=0, help="envs per wavefront (0 = auto)")
-    ap.add_argument("--nt", type=int, default=1, help="non-temporal observation stores (default 1)")
+    ap.add_argument("--nt", type=int, default=-1,
+                    help="observation store policy: 0 plain, 1 nt, 2 sc1 (default: the library's)")
     ap.add_argument("--variant", type=int, default=0, help="kernel_variant bits (A/B timing)")
     ap.add_argument("--affinity", type=int, default=0,
                     help="L2-affinity re-sort period in steps (0 = default 128, -1 = off)")
@@ -155,7 +156,7 @@ def main():
     env = BatchedTradingEnv(data if D > 1 else data[0], num_envs=N, seed=20240607,
                             env_id_base=rank * N,
                             device=local_rank, output="torch", envs_per_wave=args.epw,
-                            nontemporal_obs=bool(args.nt), kernel_variant=args.variant, affinity_period=args.affinity,
+                            **({} if args.nt < 0 else {'nontemporal_obs': args.nt}), kernel_variant=args.variant, affinity_period=args.affinity,
                             **env_kwargs(wl))
     gen = torch.Generator(device=dev)
     gen.manual_seed(99 + rank)
@@ -225,7 +226,7 @@ def main():
                        "parallelism": f"env-shard x{world}" + (
                            "" if world == 1 else " + RCCL all-gather(reward,flags"
                            + (",obs)" if args.gather_obs else ")")),
-                       "launch": info, "nontemporal_obs": bool(args.nt),
+                       "launch": info, "store_policy": int(env.cfg.nontemporal_obs),
                        "episodes_finished": episodes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -121,7 +121,7 @@ class BatchedTradingEnv:
                  name="Stock", render_mode="logs", *, autoreset="next_step",
                  episodes_between_dataset_switch=1, dyn_persist=False, seed=0,
                  env_id_base=0, device=0, output="torch", envs_per_wave=0,
-                 nontemporal_obs=True, kernel_variant=0, library_path=None, debug_flags=0,
+                 nontemporal_obs=2, kernel_variant=0, library_path=None, debug_flags=0,
                  affinity_period=0):
         assert render_mode is None or render_mode in self.metadata["render_modes"]
         if output not in ("torch", "numpy"):

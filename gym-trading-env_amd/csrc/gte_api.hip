@@ -18,13 +18,13 @@
 #include "gte_device.h"
 
 namespace gte {
-hipError_t launch_step(const Params& p, int vec, bool nt, bool coop, int stage, int blocks,
+hipError_t launch_step(const Params& p, int vec, int nt, bool coop, int stage, int blocks,
                        int threads, hipStream_t stream);
-hipError_t launch_reset(const Params& p, int vec, bool nt, bool coop, int stage, int blocks,
+hipError_t launch_reset(const Params& p, int vec, int nt, bool coop, int stage, int blocks,
                         int threads, hipStream_t stream);
 size_t lds_bytes(const Params& p, int stage);
 size_t lds_bytes_overlap(const Params& p);
-hipError_t launch_step_overlap(const Params& p, int vec, bool nt, hipStream_t stream);
+hipError_t launch_step_overlap(const Params& p, int vec, int nt, hipStream_t stream);
 struct StateSoA {
   int32_t *idx, *step, *pos, *dsi, *start, *episode, *needs_reset;
   double *asset, *fiat, *ia, *ifi, *pv, *realpos;
@@ -149,6 +149,8 @@ static int validate(const gte_config* c) {
     return fail(GTE_ERR_INVALID, "autoreset %d unknown", c->autoreset);
   if (c->episodes_between_dataset_switch < 1)
     return fail(GTE_ERR_INVALID, "episodes_between_dataset_switch must be >= 1");
+  if (c->nontemporal_obs < 0 || c->nontemporal_obs > 2)
+    return fail(GTE_ERR_INVALID, "nontemporal_obs must be 0 (plain), 1 (nt) or 2 (sc1)");
   if (c->envs_per_wave != 0 &&
       (c->envs_per_wave < 1 || c->envs_per_wave > 64 || (c->envs_per_wave & (c->envs_per_wave - 1))))
     return fail(GTE_ERR_INVALID, "envs_per_wave must be 0 or a power of two <= 64");
@@ -288,9 +290,12 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   const int64_t waves = ((int64_t)p.N + epw - 1) / epw;
   E->threads = 256;
   E->blocks = (int)((waves + 3) / 4);
-  // overlapped step kernel: windowed, W-deep rings, 64 envs per workgroup.  gte_reset keeps
-  // the classic kernel (a reset has no prediction to start from).
-  if (!(cfg->kernel_variant & 4) && !p.persist && p.W >= 2 && E->stage == 1 &&
+  // overlapped step kernel (opt-in, kernel_variant bit 4): windowed, W-deep rings, 64 envs per
+  // workgroup.  Across builds it measured 43-46 us against 42-47 us for the classic kernel
+  // (co-compiled templates perturb each other's code generation), while classic + sc1 stores
+  // was 42.7 us in every build, so that is the default.  gte_reset always uses the classic
+  // kernel (a reset has no prediction to start from).
+  if ((cfg->kernel_variant & 4) && !p.persist && p.W >= 2 && E->stage == 1 &&
       (cfg->envs_per_wave == 0 || cfg->envs_per_wave == 16) && gte::lds_bytes_overlap(p) <= 48 * 1024) {
     E->overlap = true;
     epw = 16;
@@ -432,7 +437,7 @@ int gte_reset(gte_env* E, const uint8_t* mask, const int32_t* inj_idx,
   E->term_slot = 0;
   p.term_count = E->term_base;
   p.term_count_next = E->term_base + 1;
-  HIPCHK(gte::launch_reset(p, E->vec, E->cfg.nontemporal_obs != 0, E->coop, E->stage, E->blocks,
+  HIPCHK(gte::launch_reset(p, E->vec, E->cfg.nontemporal_obs, E->coop, E->stage, E->blocks,
                            E->threads, E->stream));
   if (E->affinity_period > 0) {  // new start rows: re-sort the processing order
     HIPCHK(gte::launch_affinity_rebuild(E->p, E->d_bins, E->n_bins_per_ds, E->d_slot_of_rank,
@@ -502,9 +507,9 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
   p.term_count = E->term_base + E->term_slot;
   p.term_count_next = E->term_base + (E->term_slot ^ 1);
   if (E->overlap)
-    HIPCHK(gte::launch_step_overlap(p, E->vec, E->cfg.nontemporal_obs != 0, E->stream));
+    HIPCHK(gte::launch_step_overlap(p, E->vec, E->cfg.nontemporal_obs, E->stream));
   else
-    HIPCHK(gte::launch_step(p, E->vec, E->cfg.nontemporal_obs != 0, E->coop, E->stage, E->blocks,
+    HIPCHK(gte::launch_step(p, E->vec, E->cfg.nontemporal_obs, E->coop, E->stage, E->blocks,
                             E->threads, E->stream));
   return GTE_OK;
 }

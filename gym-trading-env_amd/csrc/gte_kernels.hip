@@ -355,10 +355,25 @@ __device__ inline uint32_t fastdiv40(uint32_t k, uint64_t magic) {
   return (uint32_t)(((uint64_t)k * magic) >> 40);
 }
 
-template <bool NT, typename T>
+// Observation store policy (gte_config.nontemporal_obs): 0 plain, 1 non-temporal,
+// 2 sc1.  tools/store_bench.hip on MI355X, 168 MB store-only: plain 26 us, nt 33 us,
+// sc1 23-24 us; plain stores evict the feature table from L2, nt/sc1 do not (an sc1
+// store drops the line from L2).  sc1 needs inline asm: the compiler does not count it
+// on vmcnt, so every place that relies on "my stores are done" waits explicitly.
+template <int NT, typename T>
 __device__ inline void store_out(T* dst, const T& v) {
-  if (NT) __builtin_nontemporal_store(v, dst);
-  else *dst = v;
+  if constexpr (NT == 2 && sizeof(T) == 16) {
+    // no "memory" clobber: nothing in the kernel reads obs back, and volatile asms keep
+    // their order among themselves (the s_waitcnt before the barrier stays behind them)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v));
+  } else if constexpr (NT == 2) {
+    const float f = __builtin_bit_cast(float, v);  // 1-element vector: plain VGPR operand
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(dst), "v"(f));
+  } else if constexpr (NT == 1) {
+    __builtin_nontemporal_store(v, dst);
+  } else {
+    *dst = v;
+  }
 }
 
 // The window's source pointer travels through LDS as a 64-bit integer, which makes the
@@ -523,7 +538,7 @@ __device__ inline void patch_dynamic(const Params& p, const WgLds& L, vec_t& v, 
 // contiguous, fully used bytes whatever the window size (also when an env's window is
 // smaller than one wave instruction, e.g. windows=None).  The env differs per lane:
 // its job is read from LDS.  U independent loads are in flight per lane.
-template <int VEC, bool NT, int STAGE, int U>
+template <int VEC, int NT, int STAGE, int U>
 __device__ inline void phase_b(const Params& p, const WgLds& L, int s_first,
                                int n_env, int lane, uint64_t vpe_magic, uint64_t fv_magic) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
@@ -584,7 +599,7 @@ __device__ inline void zero_fresh_stores(const Params& p, const WgLds& L,
 //       ~3 000 cycles of fp64 per wave whatever the number of active lanes); otherwise
 //       every wave runs phase A for its own EPW envs.
 // STAGE: how the dynamic-column values reach the copy loop (STAGE_* above).
-template <int MODE, int VEC, bool NT, bool COOP, int STAGE>
+template <int MODE, int VEC, int NT, bool COOP, int STAGE>
 __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t vpe_magic,
                                                   const uint64_t fv_magic,
                                                   const uint64_t wnd_magic) {
@@ -690,7 +705,7 @@ size_t lds_bytes_overlap(const Params& p) {
 //   EARLY: jobs are predictions and only rows < W-1 are touched, so the dynamic values
 //          come from the staged ring (or are zero); otherwise the row may be the current
 //          one, whose values are in L.cur.
-template <int VEC, bool NT, int U, bool EARLY>
+template <int VEC, int NT, int U, bool EARLY>
 __device__ inline void copy_flat(const Params& p, const OverlapLds& L, const JobRec* jobs,
                                  const int32_t* list, int s_base, const int32_t* skip_if,
                                  uint32_t n_items, uint32_t per_env, uint64_t per_env_magic,
@@ -750,7 +765,7 @@ __device__ inline void copy_flat(const Params& p, const OverlapLds& L, const Job
   }
 }
 
-template <int VEC, bool NT, int U>
+template <int VEC, int NT, int U>
 __global__ __launch_bounds__(256) void gte_step_overlap_kernel(const Params p, const uint64_t fv_magic,
                                                                const uint64_t wnd_magic,
                                                                const uint64_t early_magic,
@@ -826,7 +841,10 @@ __global__ __launch_bounds__(256) void gte_step_overlap_kernel(const Params p, c
     copy_flat<VEC, NT, U, true>(p, L, L.pjob, nullptr, s_first, nullptr, (uint32_t)n_env,
                                 VPE - FV, early_magic, 0u, 0u, 64u * U, lane, fv_magic);
   }
-  __syncthreads();  // also drains every wave's stores (vmcnt(0)) before any rewrite below
+  // every wave's early stores must have completed before any rewrite below; the sc1
+  // stores are inline asm the compiler does not count, so wait explicitly
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if (p.debug & 1) return;
   // (A) whole windows of the listed envs, (B) last rows of all the others; 4 waves interleave
   copy_flat<VEC, NT, U, false>(p, L, L.job, L.list, 0, nullptr, (uint32_t)L.n_full[0], VPE, vpe_magic,
@@ -835,7 +853,7 @@ __global__ __launch_bounds__(256) void gte_step_overlap_kernel(const Params p, c
                                (uint32_t)wib * 64u * U, 4u * 64u * U, lane, fv_magic);
 }
 
-hipError_t launch_step_overlap(const Params& p, int vec, bool nt, hipStream_t stream) {
+hipError_t launch_step_overlap(const Params& p, int vec, int nt, hipStream_t stream) {
   const uint32_t V = (uint32_t)(p.W * p.Fobs);
   const uint32_t FV = (uint32_t)p.Fobs / vec, VPE = V / vec;
   auto magic = [](uint32_t d) { return ((1ull << 40) + d - 1) / (d ? d : 1); };
@@ -847,8 +865,8 @@ hipError_t launch_step_overlap(const Params& p, int vec, bool nt, hipStream_t st
   hipLaunchKernelGGL((gte_step_overlap_kernel<VEC, NT, UU>), dim3(blocks), dim3(256), smem, stream, \
                      p, fm, wm, em, vm)
 #define GTE_O_U(VEC, NT) GTE_O(VEC, NT, 4)  /* U = 8: 49.7 us, U = 2: 44.9 us, U = 4: 43.2 us */
-  if (vec == 4) { if (nt) GTE_O_U(4, true); else GTE_O_U(4, false); }
-  else          { if (nt) GTE_O_U(1, true); else GTE_O_U(1, false); }
+  if (vec == 4) { if (nt == 2) GTE_O_U(4, 2); else if (nt == 1) GTE_O_U(4, 1); else GTE_O_U(4, 0); }
+  else          { if (nt == 2) GTE_O_U(1, 2); else if (nt == 1) GTE_O_U(1, 1); else GTE_O_U(1, 0); }
 #undef GTE_O_U
 #undef GTE_O
   return hipGetLastError();
@@ -971,7 +989,7 @@ size_t lds_bytes(const Params& p, int stage) {
 }
 
 template <int MODE>
-static hipError_t launch_mode(const Params& p, int vec, bool nt, bool coop, int stage,
+static hipError_t launch_mode(const Params& p, int vec, int nt, bool coop, int stage,
                               int blocks, int threads, hipStream_t stream) {
   const uint32_t V = (uint32_t)(p.W * p.Fobs);
   const uint64_t vm = magic40(V / vec), fm = magic40((uint32_t)p.Fobs / vec);
@@ -983,7 +1001,8 @@ static hipError_t launch_mode(const Params& p, int vec, bool nt, bool coop, int 
 #define GTE_L_ST(VEC, NT, CO) do { if (stage == STAGE_RAW) GTE_L(VEC, NT, CO, STAGE_RAW); \
     else if (stage == STAGE_LATE) GTE_L(VEC, NT, CO, STAGE_LATE); else GTE_L(VEC, NT, CO, STAGE_NONE); } while (0)
 #define GTE_L_CO(VEC, NT) do { if (coop) GTE_L_ST(VEC, NT, true); else GTE_L_ST(VEC, NT, false); } while (0)
-#define GTE_L_NT(VEC) do { if (nt) GTE_L_CO(VEC, true); else GTE_L_CO(VEC, false); } while (0)
+#define GTE_L_NT(VEC) do { if (nt == 2) GTE_L_CO(VEC, 2); else if (nt == 1) GTE_L_CO(VEC, 1); \
+                           else GTE_L_CO(VEC, 0); } while (0)
   if (vec == 4) GTE_L_NT(4); else GTE_L_NT(1);
 #undef GTE_L_NT
 #undef GTE_L_CO
@@ -999,12 +1018,12 @@ hipError_t launch_add_orders(const Params& p, const int32_t* pos_index, const do
   return hipGetLastError();
 }
 
-hipError_t launch_step(const Params& p, int vec, bool nt, bool coop, int stage, int blocks,
+hipError_t launch_step(const Params& p, int vec, int nt, bool coop, int stage, int blocks,
                        int threads, hipStream_t stream) {
   return launch_mode<MODE_STEP>(p, vec, nt, coop, stage, blocks, threads, stream);
 }
 
-hipError_t launch_reset(const Params& p, int vec, bool nt, bool coop, int stage, int blocks,
+hipError_t launch_reset(const Params& p, int vec, int nt, bool coop, int stage, int blocks,
                         int threads, hipStream_t stream) {
   return launch_mode<MODE_RESET>(p, vec, nt, coop, stage, blocks, threads, stream);
 }

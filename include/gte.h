@@ -108,13 +108,15 @@ typedef struct gte_config {
                                are keyed by global env id, so a sharded run
                                equals the unsharded one)                       */
   int32_t envs_per_wave;    /* 0 = choose automatically                        */
-  int32_t nontemporal_obs;  /* 1: non-temporal observation stores (keeps the feature
-                               table in L2/Infinity Cache; measured +4..25 %)     */
+  int32_t nontemporal_obs;  /* observation store policy: 0 plain, 1 non-temporal, 2 sc1
+                               (1 and 2 keep the feature table in L2; see
+                               store_out in csrc/gte_kernels.hip)                 */
   int32_t kernel_variant;   /* 0 = auto.  Bits for A/B timing of the kernel structure:
                                1 = every wave runs phase A for its own envs (no
                                cooperative phase A), 2 = no LDS staging of the
-                               dynamic columns, 4 = classic step kernel instead
-                               of the overlapped one (see csrc/gte_kernels.hip) */
+                               dynamic columns, 4 = overlapped step kernel (waves
+                               1-3 gather predicted windows during phase A)
+                               instead of the classic one (csrc/gte_kernels.hip) */
   int32_t debug_flags;      /* timing ablations only (results become wrong):
                                1 = skip the observation gather, 2 = skip the
                                dynamic-column patch, 8 = skip the window loads

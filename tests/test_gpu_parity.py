@@ -294,3 +294,14 @@ def test_hip_vs_oracle_shape_sweep(oracle_mod, shape, autoreset):
                          windows=windows, positions=positions, dynamic_feature_functions=kinds,
                          trading_fees=1e-3, borrow_interest_rate=1e-4,
                          max_episode_duration=max_dur, autoreset=autoreset)
+
+
+@pytest.mark.parametrize("variant,store", [(4, 1), (4, 2), (4, 0), (0, 1), (0, 0), (1, 2), (2, 2)])
+def test_hip_vs_oracle_kernel_variants(oracle_mod, variant, store):
+    """Every selectable kernel structure (classic / overlapped / per-wave phase A / no LDS
+    staging) and store policy (plain / nt / sc1) gives the same results."""
+    ds = [_synthetic(71, 3000, 30, sigma=1e-2)]
+    _compare_with_oracle(oracle_mod, ds, n_envs=6000, steps=60, seed=41, check_every=6,
+                         windows=20, positions=[-1, 0, 1], trading_fees=1e-4,
+                         borrow_interest_rate=3e-6, max_episode_duration=25,
+                         autoreset="next_step", kernel_variant=variant, nontemporal_obs=store)

@@ -42,7 +42,7 @@ def main():
         aff = int(rest[1]) if len(rest) > 1 else 0
         envs[v] = BatchedTradingEnv((feat, close), num_envs=N, seed=1, output="torch",
                                     kernel_variant=int(kv), envs_per_wave=int(epw),
-                                    nontemporal_obs=bool(int(nt)),
+                                    nontemporal_obs=int(nt),
                                     debug_flags=int(dbg[0]) if dbg else 0, affinity_period=aff,
                                     **bench.env_kwargs(wl))
         if a.region_affine:
