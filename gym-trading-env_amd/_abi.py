@@ -75,7 +75,7 @@ class GteConfig(C.Structure):
         ("kernel_variant", C.c_int32),
         ("debug_flags", C.c_int32),
         ("affinity_period", C.c_int32),
-        ("reserved1", C.c_int32),
+        ("final_obs", C.c_int32),
     ]
 
 
@@ -93,6 +93,7 @@ class GteOutputs(C.Structure):
         ("obs_elems_per_env", C.c_int64),
         ("term_slot", C.c_int32),
         ("reserved0", C.c_int32),
+        ("final_obs", C.c_void_p),
     ]
 
 

@@ -92,8 +92,20 @@ class LazyInfo(dict):
         return v
 
 
-class BatchedTradingEnv:
+try:  # soft dependency: lets `isinstance(env, gymnasium.vector.VectorEnv)` hold
+    from gymnasium.vector import VectorEnv as _VectorEnvBase  # type: ignore
+except Exception:
+    _VectorEnvBase = object
+
+
+class BatchedTradingEnv(_VectorEnvBase):
     """N independent trading environments resident in HBM.
+
+    Follows Gymnasium's vector-env conventions (docs/source/vectorize_env.rst:17-33):
+    `num_envs`, `single_observation_space` / `single_action_space`, batched
+    `observation_space` / `action_space`, `reset() -> (obs, info)`, `step(actions) ->
+    (obs, rewards, terminations, truncations, infos)` with dict-of-arrays infos and `_key`
+    masks, auto-reset in next-step (Gymnasium >= 1.0) or same-step mode.
 
     Parameters mirror `TradingEnv.__init__` (environments.py:79-93); the extra ones:
 
@@ -106,6 +118,9 @@ class BatchedTradingEnv:
     :param output: "torch" — observations/rewards/flags stay on the device as torch
         tensors (zero-copy views of the buffers the kernel writes); "numpy" — copied to
         host each step (compatibility mode).
+:param final_obs: with ``autoreset="same_step"``: keep the terminal observation of
+        every env that ends (Gymnasium's ``final_observation`` / SB3's
+        ``terminal_observation``); read it with :meth:`final_observations`.
     :param dyn_persist: keep the per-env dynamic-feature column across episodes like
         the reference's in-place write into `_obs_array` (:153-154); costs
         N*T*n_dyn*4 bytes of HBM.
@@ -122,7 +137,7 @@ class BatchedTradingEnv:
                  episodes_between_dataset_switch=1, dyn_persist=False, seed=0,
                  env_id_base=0, device=0, output="torch", envs_per_wave=0,
                  nontemporal_obs=2, kernel_variant=0, library_path=None, debug_flags=0,
-                 affinity_period=0):
+                 affinity_period=0, final_obs=False):
         assert render_mode is None or render_mode in self.metadata["render_modes"]
         if output not in ("torch", "numpy"):
             raise ValueError("output must be 'torch' or 'numpy'")
@@ -131,6 +146,8 @@ class BatchedTradingEnv:
         self.verbose, self.name, self.render_mode = verbose, name, render_mode
         self.num_envs = int(num_envs)
         self.output = output
+        self.metadata = dict(self.metadata, autoreset_mode=autoreset or "disabled")
+        self.closed = False
         self._lib = _abi.load_library(library_path)  # raises if the HIP build is missing
         self._h = C.c_void_p()
 
@@ -156,7 +173,7 @@ class BatchedTradingEnv:
             dyn_persist=dyn_persist, seed=seed, env_id_base=env_id_base, device=device,
             envs_per_wave=envs_per_wave, nontemporal_obs=nontemporal_obs,
             kernel_variant=kernel_variant, debug_flags=debug_flags,
-            affinity_period=affinity_period)
+            affinity_period=affinity_period, final_obs=final_obs)
         _abi.check(self._lib, self._lib.gte_create(C.byref(self.cfg), C.byref(self._h)))
 
         self.n_obs = first.n_static + n_dyn
@@ -233,6 +250,9 @@ class BatchedTradingEnv:
                 "term_count": torch.zeros(2, dtype=torch.int32, device=dev),  # two slots
                 "term_ids": torch.zeros(N, dtype=torch.int32, device=dev),
             }
+            if self.cfg.final_obs:
+                self._t["final_obs"] = torch.zeros((N,) + self.obs_shape, dtype=torch.float32,
+                                                   device=dev)
             torch.cuda.synchronize(dev)
             b = _abi.GteOutputs()
             for k, t in self._t.items():
@@ -261,17 +281,31 @@ class BatchedTradingEnv:
         """Host copy of one output array of the last step/reset."""
         N = self.num_envs
         spec = {"obs": (np.float32, N * int(np.prod(self.obs_shape))),
+                "final_obs": (np.float32, N * int(np.prod(self.obs_shape))),
                 "reward": (np.float32, N), "reward64": (np.float64, N),
                 "terminated": (np.uint8, N), "truncated": (np.uint8, N),
                 "term_count": (np.int32, 2), "term_ids": (np.int32, N)}[name]
         a = self._to_host(getattr(self._out, name), *spec)
-        return a.reshape((N,) + self.obs_shape) if name == "obs" else a
+        return a.reshape((N,) + self.obs_shape) if name in ("obs", "final_obs") else a
 
     def terminal_ids(self) -> np.ndarray:
         """Ids of the envs whose episode ended in the last step (sorted)."""
         _abi.check(self._lib, self._lib.gte_get_outputs(self._h, C.byref(self._out)))
         n = int(self.read_output("term_count")[self._out.term_slot])
         return np.sort(self.read_output("term_ids")[:n])
+
+    def final_observations(self):
+        """(env ids, terminal observations) of the envs that ended in the last step — the
+        observation `TradingEnv.step` returned for them before the same-step reset
+        (needs ``autoreset="same_step", final_obs=True``).  Torch mode: rows gathered on
+        the device."""
+        if not self.cfg.final_obs:
+            raise ValueError("constructed without final_obs=True")
+        ids = self.terminal_ids()
+        if self.output == "torch":
+            idx = self._torch.from_numpy(ids.astype(np.int64)).to(self._t["final_obs"].device)
+            return ids, self._t["final_obs"][idx]
+        return ids, self.read_output("final_obs")[ids]
 
     def episode_metrics(self, env_ids=None) -> dict:
         """Episode-end metrics of `calculate_metrics` (environments.py:279-286) for the envs
@@ -403,10 +437,11 @@ class BatchedTradingEnv:
         _abi.check(self._lib, self._lib.gte_timer_stop(self._h, C.byref(ms)))
         return ms.value
 
-    def close(self):
+    def close(self, **kwargs):
         if getattr(self, "_h", None) and self._h.value:
             self._lib.gte_destroy(self._h)
             self._h = C.c_void_p()
+        self.closed = True
 
     def __del__(self):
         try:

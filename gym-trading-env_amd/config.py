@@ -84,7 +84,8 @@ def make_config(*, n_envs: int, n_static: int, n_datasets: int = 1,
                 dyn_persist: bool = False, seed: int = 0, env_id_base: int = 0,
                 device: int = 0, envs_per_wave: int = 0,
                 nontemporal_obs: int = 2, kernel_variant: int = 0,
-                debug_flags: int = 0, affinity_period: int = 0) -> _abi.GteConfig:
+                debug_flags: int = 0, affinity_period: int = 0,
+                final_obs: bool = False) -> _abi.GteConfig:
     positions = list(positions)
     if not 0 < len(positions) <= _abi.GTE_MAX_POSITIONS:
         raise ValueError(f"1..{_abi.GTE_MAX_POSITIONS} positions supported")
@@ -140,4 +141,7 @@ def make_config(*, n_envs: int, n_static: int, n_datasets: int = 1,
     cfg.kernel_variant = int(kernel_variant)
     cfg.debug_flags = int(debug_flags)
     cfg.affinity_period = int(affinity_period)
+    if final_obs and _AUTORESET_BY_NAME[autoreset] != _abi.AUTORESET_SAME_STEP:
+        raise ValueError("final_obs needs autoreset='same_step'")
+    cfg.final_obs = int(bool(final_obs))
     return cfg

@@ -151,6 +151,8 @@ static int validate(const gte_config* c) {
     return fail(GTE_ERR_INVALID, "episodes_between_dataset_switch must be >= 1");
   if (c->nontemporal_obs < 0 || c->nontemporal_obs > 2)
     return fail(GTE_ERR_INVALID, "nontemporal_obs must be 0 (plain), 1 (nt) or 2 (sc1)");
+  if (c->final_obs && c->autoreset != GTE_AUTORESET_SAME_STEP)
+    return fail(GTE_ERR_INVALID, "final_obs needs autoreset = same-step");
   if (c->envs_per_wave != 0 &&
       (c->envs_per_wave < 1 || c->envs_per_wave > 64 || (c->envs_per_wave & (c->envs_per_wave - 1))))
     return fail(GTE_ERR_INVALID, "envs_per_wave must be 0 or a power of two <= 64");
@@ -239,6 +241,7 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   chk(dev_alloc(E, &E->soa.ia, N)); chk(dev_alloc(E, &E->soa.ifi, N));
   chk(dev_alloc(E, &E->soa.pv, N)); chk(dev_alloc(E, &E->soa.realpos, N));
   chk(dev_alloc(E, &E->owned.obs, N * p.W * p.Fobs));
+  if (cfg->final_obs) chk(dev_alloc(E, &E->owned.final_obs, N * p.W * p.Fobs));
   chk(dev_alloc(E, &E->owned.reward, N)); chk(dev_alloc(E, &E->owned.reward64, N));
   chk(dev_alloc(E, &E->owned.terminated, N)); chk(dev_alloc(E, &E->owned.truncated, N));
   chk(dev_alloc(E, &E->owned.term_count, 2)); chk(dev_alloc(E, &E->owned.term_ids, N));
@@ -260,6 +263,7 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   p.positions = d_pos;
   p.ds = E->d_ds;
   E->owned.obs_elems_per_env = (int64_t)p.W * p.Fobs;
+  p.final_obs = E->owned.final_obs;
   p.obs = E->owned.obs; p.reward = E->owned.reward; p.reward64 = E->owned.reward64;
   p.terminated = E->owned.terminated; p.truncated = E->owned.truncated;
   E->term_base = E->owned.term_count; p.term_ids = E->owned.term_ids;
@@ -295,7 +299,7 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   // (co-compiled templates perturb each other's code generation), while classic + sc1 stores
   // was 42.7 us in every build, so that is the default.  gte_reset always uses the classic
   // kernel (a reset has no prediction to start from).
-  if ((cfg->kernel_variant & 4) && !p.persist && p.W >= 2 && E->stage == 1 &&
+  if ((cfg->kernel_variant & 4) && !cfg->final_obs && !p.persist && p.W >= 2 && E->stage == 1 &&
       (cfg->envs_per_wave == 0 || cfg->envs_per_wave == 16) && gte::lds_bytes_overlap(p) <= 48 * 1024) {
     E->overlap = true;
     epw = 16;
@@ -554,6 +558,7 @@ int gte_get_outputs(gte_env* E, gte_outputs* out) {
   out->obs_elems_per_env = (int64_t)p.W * p.Fobs;
   out->term_slot = E->term_slot;
   out->reserved0 = 0;
+  out->final_obs = p.final_obs;
   return GTE_OK;
 }
 
@@ -563,6 +568,7 @@ int gte_bind_outputs(gte_env* E, const gte_outputs* b) {
   Params& p = E->p;
   if (b->obs && ((uintptr_t)b->obs & 15)) return fail(GTE_ERR_INVALID, "obs must be 16-byte aligned");
   p.obs = b->obs ? b->obs : E->owned.obs;
+  if (E->cfg.final_obs) p.final_obs = b->final_obs ? b->final_obs : E->owned.final_obs;
   p.reward = b->reward ? b->reward : E->owned.reward;
   p.reward64 = b->reward64 ? b->reward64 : E->owned.reward64;
   p.terminated = b->terminated ? b->terminated : E->owned.terminated;

@@ -56,6 +56,7 @@ struct Params {
   double* lo_limit;     // f64 [N, P]
   uint8_t* lo_persist;  // u8  [N, P]
   // --- outputs
+  float* final_obs;  // f32 [N, W, Fobs] or null: terminal observations (same-step mode)
   float* obs;
   float* reward;
   double* reward64;
@@ -199,6 +200,16 @@ struct ObsJob {
   int32_t n_zero;     // leading window rows whose dynamic columns read as zero
   int32_t flags;      // bit0: copy the window; bit1: zero the env's dynamic store
   float cur[GTE_MAX_DYN];  // dynamic features of the current row (f32, :154)
+};
+
+// Same-step auto-reset with final_obs: the window of the TERMINAL state, gathered into
+// final_obs[env] next to the reset observation.
+struct FinalJob {
+  const float* src;
+  int32_t slot0, n_zero, flags;   // flags bit0: this env ended in this launch
+  int32_t clob_slot;              // ring slot the reset's current row overwrote ...
+  float clob[GTE_MAX_DYN];        // ... and what it held before
+  float cur[GTE_MAX_DYN];         // dynamic features of the terminal row
 };
 
 }  // namespace gte

@@ -243,7 +243,8 @@ struct OldState {  // what phase A started from (for the prediction check)
 
 template <int MODE>
 __device__ inline void phase_a(const Params& p, int e, bool active, int lane, ObsJob& job,
-                               OldState* old = nullptr) {
+                               OldState* old = nullptr, FinalJob* fin = nullptr) {
+  if (fin) fin->flags = 0;
   job.src = nullptr; job.slot0 = 0; job.n_zero = 0; job.idx = 0; job.flags = 0;
 #pragma unroll
   for (int i = 0; i < GTE_MAX_DYN; ++i) job.cur[i] = 0.0f;
@@ -324,9 +325,25 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
       ended = done || trunc;
       if (ended) s.needs_reset = 1;
       if (ended && p.autoreset == GTE_AUTORESET_SAME_STEP) {
+        // the reference's step() runs _get_obs (:272) before any wrapper resets the env:
+        // write the terminal row's dynamic features, remember the terminal window
+        ObsJob term;
+        make_job(p, e, s, false, term);
         int32_t qi, qp, qd;
         pop_injection(p, e, s, qi, qp, qd);
         do_reset(p, e, qi, qp, qd, s, fresh);
+        if (fin && p.final_obs) {
+          fin->src = term.src; fin->slot0 = term.slot0; fin->n_zero = term.n_zero; fin->flags = 1;
+          // the reset's current row is about to overwrite one ring slot the terminal window
+          // may still need: keep its old content (this lane wrote/reads it in program order)
+          const int64_t cs = p.persist ? (int64_t)s.idx : (int64_t)(s.idx % p.W);
+          fin->clob_slot = (int32_t)cs;
+#pragma unroll
+          for (int i = 0; i < GTE_MAX_DYN; ++i) {
+            fin->cur[i] = term.cur[i];
+            fin->clob[i] = (i < p.nd) ? p.ring[((int64_t)e * p.depth + cs) * p.nd + i] : 0.0f;
+          }
+        }
       }
     }
     store_state(p, e, s);
@@ -422,14 +439,16 @@ struct WgLds {
   JobRec* job;      // [EPB]
   int32_t* idx;     // [EPB] current row (persist mode's zero-fill needs it)
   float* cur;       // [EPB][GTE_MAX_DYN] dynamic features of the current row
+  FinalJob* fin;    // [EPB] terminal windows (only when p.final_obs)
   float* staged;    // [EPB][W][nd]
 };
 
-__device__ inline WgLds carve_lds(unsigned char* base, int EPB) {
+__device__ inline WgLds carve_lds(unsigned char* base, int EPB, bool with_final) {
   WgLds L;
   L.job = (JobRec*)base;                   base += 16 * EPB;
   L.cur = (float*)base;                    base += 4 * GTE_MAX_DYN * EPB;
   L.idx = (int32_t*)base;                  base += 4 * EPB;
+  L.fin = (FinalJob*)base;                 base += with_final ? sizeof(FinalJob) * EPB : 0;
   L.staged = (float*)base;
   return L;
 }
@@ -594,6 +613,55 @@ __device__ inline void zero_fresh_stores(const Params& p, const WgLds& L,
   }
 }
 
+// Terminal observations (same-step auto-reset + final_obs): the wave copies the terminal
+// window of each of its envs that ended in this launch into final_obs[env].  Rare, so one
+// env at a time.  Earlier rows' dynamic values come from the env's ring in global memory,
+// except the terminal row itself (fin.cur) and the slot the reset overwrote (fin.clob).
+template <int VEC>
+__device__ inline void final_windows(const Params& p, const WgLds& L, int s_first, int n_env,
+                                     int lane, uint64_t fv_magic) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  const uint32_t V = (uint32_t)(p.W * p.Fobs), VPE = V / VEC, FV = (uint32_t)p.Fobs / VEC;
+  for (int el = 0; el < n_env; ++el) {
+    const int s = s_first + el;
+    if (!(L.fin[s].flags & 1)) continue;  // wave-uniform
+    const FinalJob f = L.fin[s];
+    const int64_t env = L.job[s].env;
+    const float* ring_e = p.ring + env * p.depth * p.nd;
+    float* dst = p.final_obs + env * V;
+    for (uint32_t j = (uint32_t)lane; j < VPE; j += 64u) {
+      vec_t v = load_global<vec_t>((uint64_t)f.src, (int64_t)j);
+      const uint32_t w = fastdiv40(j, fv_magic);
+      const int col = (int)(j - w * FV) * VEC;
+      if (col + VEC > p.Fs) {
+        int32_t slot = f.slot0 + (int32_t)w;
+        if (!p.persist && slot >= p.W) slot -= p.W;
+        float x[GTE_MAX_DYN];
+#pragma unroll
+        for (int i = 0; i < GTE_MAX_DYN; ++i) {
+          x[i] = 0.0f;
+          if (i < p.nd) {
+            if ((int)w == p.W - 1) x[i] = f.cur[i];
+            else if ((int)w < f.n_zero) x[i] = 0.0f;
+            else if (slot == f.clob_slot) x[i] = f.clob[i];
+            else x[i] = ring_e[(int64_t)slot * p.nd + i];
+          }
+        }
+        if constexpr (VEC == 4) {
+          set_tail(v, p.nd, x);
+        } else {
+          const int i = col - p.Fs;
+          float r = x[0];
+#pragma unroll
+          for (int k = 1; k < GTE_MAX_DYN; ++k) r = (i == k) ? x[k] : r;
+          v = r;
+        }
+      }
+      *(vec_t*)(dst + (int64_t)j * VEC) = v;
+    }
+  }
+}
+
 // COOP: wave 0 of the workgroup runs phase A for all 4*EPW (<= 64) envs of the
 //       workgroup, one per lane at full lane utilisation (phase A is VALU-issue bound:
 //       ~3 000 cycles of fp64 per wave whatever the number of active lanes); otherwise
@@ -613,7 +681,7 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
   const int wg_first = blockIdx.x * EPB;
   if (wg_first >= p.N) return;  // whole workgroup exits together (before any barrier)
   const int n_wg = min(EPB, p.N - wg_first);
-  const WgLds L = carve_lds(gte_smem, EPB);
+  const WgLds L = carve_lds(gte_smem, EPB, p.final_obs != nullptr);
   const int s_first = wib * p.epw;
   const int n_env = min(p.epw, n_wg - s_first);
   // which env each slot of this wave processes: the identity, or the L2-affinity
@@ -636,8 +704,10 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
     const bool active = owns && s < n_wg;
     const int e = active ? (p.perm ? p.perm[wg_first + s] : wg_first + s) : 0;
     ObsJob job;
-    phase_a<MODE>(p, e, active, lane, job);
+    FinalJob fin;
+    phase_a<MODE>(p, e, active, lane, job, nullptr, p.final_obs ? &fin : nullptr);
     if (owns) publish_job(L, s, job);  // slots past the last env get flags = 0
+    if (owns && p.final_obs) L.fin[s] = fin;
   }
   __syncthreads();
 
@@ -653,6 +723,7 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   phase_b<VEC, NT, STAGE, 4>(p, L, s_first, n_env, lane, vpe_magic, fv_magic);
+  if (MODE == MODE_STEP && p.final_obs) final_windows<VEC>(p, L, s_first, n_env, lane, fv_magic);
 }
 
 // ---------------------------------------------------------------------------
@@ -983,7 +1054,7 @@ static uint64_t magic40(uint32_t d) { return ((1ull << 40) + d - 1) / d; }
 
 size_t lds_bytes(const Params& p, int stage) {
   const size_t EPB = (size_t)p.epw * 4;
-  size_t b = EPB * (16 + 4 * GTE_MAX_DYN + 4);
+  size_t b = EPB * (16 + 4 * GTE_MAX_DYN + 4) + (p.final_obs ? EPB * sizeof(FinalJob) : 0);
   if (stage) b += EPB * (size_t)p.W * (size_t)(p.nd ? p.nd : 1) * 4;
   return b;
 }

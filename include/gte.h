@@ -125,7 +125,10 @@ typedef struct gte_config {
                                envs are re-sorted by (dataset, table region) so that
                                each XCD's L2 serves one region (speed only; results
                                do not depend on it).  0 = default (128), -1 = off   */
-  int32_t reserved1;
+  int32_t final_obs;        /* 1 (needs autoreset = same-step): keep the terminal
+                               observation of every env that ends, in
+                               gte_outputs.final_obs (Gymnasium `final_observation`,
+                               SB3 `terminal_observation`)                        */
 } gte_config;
 
 /* Device pointers of the per-step return values of TradingEnv.step
@@ -144,6 +147,9 @@ typedef struct gte_outputs {
   int64_t  obs_elems_per_env; /* W*F_obs                                       */
   int32_t  term_slot;  /* which slot the last launch used (set by gte_get_outputs) */
   int32_t  reserved0;
+  float*   final_obs;  /* f32 [N, W, F_obs] or NULL: row e holds the terminal observation
+                          of env e after a step in which e ended (same-step mode with
+                          gte_config.final_obs); other rows keep older contents     */
 } gte_outputs;
 
 /* Device pointers of the per-env state (struct of arrays), i.e. the fields of

@@ -40,6 +40,7 @@ typedef struct gto_env {
   double *asset, *fiat, *ia, *ifi, *pv, *realpos;
   float* ring; /* [N, depth, nd] */
   /* outputs */
+  float* final_obs; /* [N, W, Fobs] terminal observations (same-step mode, cfg.final_obs) */
   float* obs;
   float* reward;
   double* reward64;
@@ -375,6 +376,14 @@ static int step_one(gto_env* E, int32_t e, int32_t action) {
   int ended = done || trunc;
   if (ended) E->needs_reset[e] = 1;
   if (ended && c->autoreset == GTE_AUTORESET_SAME_STEP) {
+    /* the reference's step() runs _get_obs at :272 before any wrapper resets the env: the
+     * terminal row's dynamic features are written (matters for dyn_persist), and that
+     * observation is what Gymnasium / SB3 report as the final one */
+    get_obs(E, e);
+    if (c->final_obs) {
+      memcpy(E->final_obs + (int64_t)e * E->W * E->Fobs, E->obs + (int64_t)e * E->W * E->Fobs,
+             sizeof(float) * E->W * E->Fobs);
+    }
     int32_t qi, qp, qd;
     pop_injection(E, e, &qi, &qp, &qd);
     do_reset(E, e, qi, qp, qd); /* writes the reset observation */
@@ -422,6 +431,7 @@ gto_env* gto_create(const gte_config* cfg) {
   E->terminated = (uint8_t*)zalloc(N);
   E->truncated = (uint8_t*)zalloc(N);
   E->obs = (float*)zalloc(sizeof(float) * N * E->W * E->Fobs);
+  E->final_obs = (float*)zalloc(sizeof(float) * N * E->W * E->Fobs);
   return E;
 }
 
@@ -534,6 +544,7 @@ int gto_step(gto_env* E, const int32_t* actions, int32_t threads) {
 #define GETTER(type, name, field) \
   type* gto_get_##name(gto_env* E) { return E->field; }
 GETTER(float, obs, obs)
+GETTER(float, final_obs, final_obs)
 GETTER(float, reward, reward)
 GETTER(double, reward64, reward64)
 GETTER(uint8_t, terminated, terminated)
@@ -574,7 +585,7 @@ void gto_destroy(gto_env* E) {
   free(E->idx); free(E->step); free(E->pos); free(E->ds); free(E->start);
   free(E->episode); free(E->needs_reset); free(E->eps_on_ds); free(E->n_picks);
   free(E->asset); free(E->fiat); free(E->ia); free(E->ifi); free(E->pv);
-  free(E->realpos); free(E->ring); free(E->obs); free(E->reward);
+  free(E->realpos); free(E->ring); free(E->obs); free(E->final_obs); free(E->reward);
   free(E->reward64); free(E->terminated); free(E->truncated); free(E->term_ids);
   free(E->q_idx); free(E->q_pos); free(E->q_ds); free(E->q_head);
   free(E);

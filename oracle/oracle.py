@@ -51,7 +51,7 @@ def lib() -> C.CDLL:
         l.gto_destroy.argtypes = [C.c_void_p]
         l.gto_term_count.argtypes = [C.c_void_p]
         l.gto_term_count.restype = C.c_int32
-        for n in _I32 + _F64 + ("obs", "reward", "reward64", "terminated", "truncated", "term_ids"):
+        for n in _I32 + _F64 + ("final_obs", "obs", "reward", "reward64", "terminated", "truncated", "term_ids"):
             f = getattr(l, "gto_get_" + n)
             f.restype = C.c_void_p
             f.argtypes = [C.c_void_p]
@@ -137,6 +137,11 @@ class OracleEnv:
     def obs(self):
         shape = (self.N, self.W, self.F) if self.cfg.window > 0 else (self.N, self.F)
         return self._view("obs", np.float32, shape)
+
+    @property
+    def final_obs(self):
+        shape = (self.N, self.W, self.F) if self.cfg.window > 0 else (self.N, self.F)
+        return self._view("final_obs", np.float32, shape)
 
     reward = property(lambda s: s._view("reward", np.float32, (s.N,)))
     reward64 = property(lambda s: s._view("reward64", np.float64, (s.N,)))
