@@ -42,3 +42,62 @@ def test_sharded_env_single_rank_nccl(oracle_mod):
         env.close()
     finally:
         dist.destroy_process_group()
+
+
+def _rank_main(rank, world, port, out_dir):
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gym_trading_env_amd.distributed import ShardedTradingEnv
+        torch.cuda.set_device(0)
+        rng = np.random.default_rng(0)
+        T, Fs, G = 300, 6, 1024
+        close = 100 * np.exp(np.cumsum(rng.normal(0, 1e-2, T)))
+        feat = rng.normal(0, 1, (T, Fs)).astype(np.float32)
+        kw = dict(positions=[-1, 0, 1], windows=5, trading_fees=1e-4, max_episode_duration=20,
+                  autoreset="next_step", seed=4)
+        env = ShardedTradingEnv((feat, close), G, device=0, gather_obs=True, **kw)
+        env.reset()
+        acts = np.random.default_rng(1).integers(-1, 3, (30, G)).astype(np.int32)
+        rec = []
+        for k in range(30):
+            a = torch.from_numpy(acts[k, env.first:env.first + env.n_local]).cuda()
+            obs, reward, term, trunc, _ = env.step(a)
+            rec.append((obs.cpu().numpy().copy(), reward.cpu().numpy().reshape(-1).copy(),
+                        term.cpu().numpy().reshape(-1).copy(), trunc.cpu().numpy().reshape(-1).copy()))
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "g.npz"), obs=np.stack([r[0] for r in rec]),
+                     reward=np.stack([r[1] for r in rec]), term=np.stack([r[2] for r in rec]),
+                     trunc=np.stack([r[3] for r in rec]), acts=acts, feat=feat, close=close)
+        env.close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_unsharded_oracle(tmp_path, oracle_mod):
+    """world_size 2 for real: both ranks run their shard through the HIP kernels on the
+    box's single GPU; the return gather goes through gloo (RCCL refuses two ranks on one
+    device).  The gathered (obs, reward, flags) must equal the unsharded oracle."""
+    import torch.multiprocessing as mp
+    from gym_trading_env_amd.config import make_config
+    port = 29700 + os.getpid() % 1000
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g = np.load(tmp_path / "g.npz")
+    full = np.zeros((300, 8), np.float32)
+    full[:, :6] = g["feat"]
+    cfg = make_config(n_envs=1024, n_static=6, positions=[-1, 0, 1], windows=5, trading_fees=1e-4,
+                      max_episode_duration=20, autoreset="next_step", seed=4)
+    ora = oracle_mod.OracleEnv(cfg, [(full, g["close"])])
+    ora.reset()
+    for k in range(30):
+        ora.step(g["acts"][k])
+        np.testing.assert_array_equal(g["obs"][k], ora.obs)
+        np.testing.assert_array_equal(g["reward"][k], ora.reward)
+        np.testing.assert_array_equal(g["term"][k], ora.terminated.astype(bool))
+        np.testing.assert_array_equal(g["trunc"][k], ora.truncated.astype(bool))
