@@ -235,6 +235,17 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
+            # the reference's OWN Python step() cannot run on this box (its files do not
+            # travel); quote the timing taken in the build container (tools/time_reference.py)
+            rp = os.path.join(ROOT, "profiles", "reference_cpu_timing.json")
+            if os.path.exists(rp):
+                try:
+                    ref = json.load(open(rp))
+                    out["cpu_baseline"]["reference_python"] = {
+                        "where": ref["where"], "cpu": ref["cpu"], "cores": ref["cores"],
+                        "env_steps_per_s": ref["shapes"].get(args.workload)}
+                except Exception:
+                    pass
         print(json.dumps(out))
     env.close()
     if world > 1:
