@@ -8,7 +8,6 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
-#include <utility>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -30,16 +29,17 @@ struct StateSoA {
   int32_t *idx, *step, *pos, *dsi, *start, *episode, *needs_reset;
   double *asset, *fiat, *ia, *ifi, *pv, *realpos;
 };
-hipError_t launch_extract_state(const Params& p, const StateSoA& o, hipStream_t stream);
-hipError_t launch_affinity_rebuild(const Params& p, const StateArrays& nst, int32_t* bins,
-                                   int n_bins_per_ds, const int32_t* slot_of_rank,
-                                   int32_t* perm_new, int32_t* slot_of_env, hipStream_t stream);
+hipError_t launch_extract_state(const EnvRec* rec, int n, const StateSoA& o, hipStream_t stream);
+hipError_t launch_rewind_queue(EnvRec* rec, int n, hipStream_t stream);
+hipError_t launch_affinity_rebuild(const Params& p, int32_t* bins, int n_bins_per_ds,
+                                   const int32_t* slot_of_rank, int32_t* perm_out,
+                                   hipStream_t stream);
 hipError_t launch_add_orders(const Params& p, const int32_t* pos_index, const double* limit,
                              const uint8_t* persistent, hipStream_t stream);
 }  // namespace gte
 
 using gte::DatasetDesc;
-using gte::StateArrays;
+using gte::EnvRec;
 using gte::Params;
 
 static thread_local std::string g_err = "";
@@ -92,10 +92,7 @@ struct gte_env {
   int affinity_period = 0;       // 0 = off
   int steps_since_rebuild = 0;
   int n_bins_per_ds = 0;
-  int32_t* d_perm = nullptr;      // current slot -> env (null until the first rebuild)
-  int32_t* d_perm_alt = nullptr;  // the buffer the next rebuild writes
-  int32_t* d_slot_of_env = nullptr;
-  StateArrays st_alt = {};        // second set of state arrays (the rebuild moves the state)
+  int32_t* d_perm = nullptr;
   int32_t* d_slot_of_rank = nullptr;
   int32_t* d_bins = nullptr;
   gte::StateSoA soa = {};  // host-facing struct-of-arrays mirrors (gte_get_state)
@@ -235,16 +232,7 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   E->stream = E->own_stream;
   chk(hipEventCreate(&E->ev0) == hipSuccess && hipEventCreate(&E->ev1) == hipSuccess
           ? GTE_OK : fail(GTE_ERR_HIP, "hipEventCreate failed"));
-  auto alloc_state = [&](StateArrays& a) {  // zero-filled: every counter starts at 0
-    chk(dev_alloc(E, &a.idx, N)); chk(dev_alloc(E, &a.step, N)); chk(dev_alloc(E, &a.pos, N));
-    chk(dev_alloc(E, &a.dsi, N)); chk(dev_alloc(E, &a.start, N)); chk(dev_alloc(E, &a.episode, N));
-    chk(dev_alloc(E, &a.needs_reset, N)); chk(dev_alloc(E, &a.eps_on_ds, N));
-    chk(dev_alloc(E, &a.n_picks, N)); chk(dev_alloc(E, &a.q_head, N)); chk(dev_alloc(E, &a.lo_n, N));
-    chk(dev_alloc(E, &a.asset, N)); chk(dev_alloc(E, &a.fiat, N)); chk(dev_alloc(E, &a.ia, N));
-    chk(dev_alloc(E, &a.ifi, N)); chk(dev_alloc(E, &a.pv, N)); chk(dev_alloc(E, &a.realpos, N));
-    chk(dev_alloc(E, &a.close_cur, N)); chk(dev_alloc(E, &a.close_next, N));
-  };
-  alloc_state(p.st);
+  chk(dev_alloc(E, &p.rec, N));  // zero-filled: every counter starts at 0
   chk(dev_alloc(E, &E->soa.idx, N)); chk(dev_alloc(E, &E->soa.step, N));
   chk(dev_alloc(E, &E->soa.pos, N)); chk(dev_alloc(E, &E->soa.dsi, N));
   chk(dev_alloc(E, &E->soa.start, N)); chk(dev_alloc(E, &E->soa.episode, N));
@@ -337,9 +325,6 @@ int gte_create(const gte_config* cfg, gte_env** out) {
       E->n_bins_per_ds = nb;
       int rc2 = GTE_OK;
       if (rc2 == GTE_OK) rc2 = dev_alloc(E, &E->d_perm, N, false);
-      if (rc2 == GTE_OK) rc2 = dev_alloc(E, &E->d_perm_alt, N, false);
-      if (rc2 == GTE_OK) rc2 = dev_alloc(E, &E->d_slot_of_env, N, false);
-      if (rc2 == GTE_OK) { alloc_state(E->st_alt); rc2 = rc; }
       if (rc2 == GTE_OK) rc2 = dev_alloc(E, &E->d_slot_of_rank, N, false);
       if (rc2 == GTE_OK) rc2 = dev_alloc(E, &E->d_bins, (size_t)p.D * nb);
       if (rc2 == GTE_OK && hipMemcpy(E->d_slot_of_rank, slot_of_rank.data(), sizeof(int32_t) * N,
@@ -390,7 +375,6 @@ int gte_upload_dataset(gte_env* E, int32_t d, const float* feat, const double* c
   E->h_ds[d] = DatasetDesc{(const float*)dev[0], (const double*)dev[1], (const double*)dev[2],
                            (const double*)dev[3], T};
   HIPCHK(hipMemcpy(E->d_ds, E->h_ds.data(), sizeof(DatasetDesc) * p.D, hipMemcpyHostToDevice));
-  E->p.ds0 = E->h_ds[0];
   return GTE_OK;
 }
 
@@ -435,19 +419,6 @@ static int check_injection(const gte_env* E, size_t count, const int32_t* idx, c
   return GTE_OK;
 }
 
-// Re-sort the processing order by (dataset, table region) and move the slot-ordered state
-// into the other set of arrays; afterwards E->p points at the new order.
-static int rebuild_affinity(gte_env* E) {
-  int32_t* perm_new = (E->p.perm == E->d_perm) ? E->d_perm_alt : E->d_perm;
-  HIPCHK(gte::launch_affinity_rebuild(E->p, E->st_alt, E->d_bins, E->n_bins_per_ds,
-                                      E->d_slot_of_rank, perm_new, E->d_slot_of_env, E->stream));
-  std::swap(E->p.st, E->st_alt);
-  E->p.perm = perm_new;
-  E->p.slot_of_env = E->d_slot_of_env;
-  E->steps_since_rebuild = 0;
-  return GTE_OK;
-}
-
 static int stage(gte_env* E, void* dst, const void* src, size_t bytes) {
   HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, E->stream));
   return GTE_OK;
@@ -472,7 +443,12 @@ int gte_reset(gte_env* E, const uint8_t* mask, const int32_t* inj_idx,
   p.term_count_next = E->term_base + 1;
   HIPCHK(gte::launch_reset(p, E->vec, E->cfg.nontemporal_obs, E->coop, E->stage, E->blocks,
                            E->threads, E->stream));
-  if (E->affinity_period > 0) TRY(rebuild_affinity(E));  // new start rows: re-sort
+  if (E->affinity_period > 0) {  // new start rows: re-sort the processing order
+    HIPCHK(gte::launch_affinity_rebuild(E->p, E->d_bins, E->n_bins_per_ds, E->d_slot_of_rank,
+                                        E->d_perm, E->stream));
+    E->p.perm = E->d_perm;
+    E->steps_since_rebuild = 0;
+  }
   // host staging buffers may be reused by the caller right away: pageable copies above
   // are complete on return, but keep the contract simple and explicit
   HIPCHK(hipStreamSynchronize(E->stream));
@@ -505,7 +481,7 @@ int gte_set_autoreset_injection(gte_env* E, int32_t n, const int32_t* inj_idx,
   TRY(put(&E->d_q_pos, inj_pos_index, &p.q_pos));
   TRY(put(&E->d_q_ds, inj_dataset, &p.q_ds));
   p.q_n = n;
-  HIPCHK(hipMemsetAsync(p.st.q_head, 0, sizeof(int32_t) * p.N, E->stream));
+  HIPCHK(gte::launch_rewind_queue(p.rec, p.N, E->stream));
   HIPCHK(hipStreamSynchronize(E->stream));
   HIPCHK(hipDeviceSynchronize());
   return GTE_OK;
@@ -515,10 +491,13 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
   if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
   if (!E->was_reset) return fail(GTE_ERR_STATE, "gte_step before gte_reset");
   if (!actions) return fail(GTE_ERR_INVALID, "actions is NULL");
-  // envs drift one row per step and ~1/duration of them jump at a reset: re-sort now and then
-  // (4 tiny launches, stream-ordered between two steps)
-  if (E->affinity_period > 0 && ++E->steps_since_rebuild >= E->affinity_period)
-    TRY(rebuild_affinity(E));
+  if (E->affinity_period > 0 && ++E->steps_since_rebuild >= E->affinity_period) {
+    // envs drift one row per step and ~1/duration of them jump at a reset: re-sort now and
+    // then (4 tiny launches, stream-ordered between two steps)
+    HIPCHK(gte::launch_affinity_rebuild(E->p, E->d_bins, E->n_bins_per_ds, E->d_slot_of_rank,
+                                        E->d_perm, E->stream));
+    E->steps_since_rebuild = 0;
+  }
   Params p = E->p;
   if (actions_on_device) {
     p.actions = actions;
@@ -551,7 +530,7 @@ int gte_add_limit_orders(gte_env* E, const int32_t* pos_index, const double* lim
   for (size_t i = 0; i < N; ++i)
     if (pos_index[i] >= p.P) return fail(GTE_ERR_INVALID, "pos_index[%zu] out of range", i);
   HIPCHK(hipSetDevice(E->cfg.device));
-  if (!p.lo_pos) {  // first use: allocate the order tables (the counts live in the state arrays)
+  if (!p.lo_pos) {  // first use: allocate the order tables (the counts live in EnvRec)
     int32_t* lo_pos = nullptr;
     TRY(dev_alloc(E, &lo_pos, N * p.P));
     TRY(dev_alloc(E, &p.lo_limit, N * p.P));
@@ -607,7 +586,7 @@ int gte_get_state(gte_env* E, gte_state_view* out) {
   // the state lives in 128-byte records; snapshot it into struct-of-arrays mirrors
   // (stream-ordered: the views reflect every launch enqueued before this call)
   HIPCHK(hipSetDevice(E->cfg.device));
-  HIPCHK(gte::launch_extract_state(E->p, E->soa, E->stream));
+  HIPCHK(gte::launch_extract_state(E->p.rec, E->p.N, E->soa, E->stream));
   const gte::StateSoA& o = E->soa;
   out->idx = o.idx; out->step = o.step; out->position_index = o.pos;
   out->dataset_index = o.dsi; out->start_idx = o.start; out->episode = o.episode;

@@ -23,20 +23,17 @@ struct DatasetDesc {
   int64_t T;
 };
 
-// Per-env state: a struct of arrays indexed by PROCESSING SLOT, not by env id.  Envs are
-// processed in an L2-affinity order (slot -> env, see gte_kernels.hip); storing the state in
-// that order keeps every access of phase A coalesced (measured: phase A alone 6 us with
-// coalesced arrays, 9.7 us with 128-byte records, 12.7 us with records reached through the
-// permutation).  When the order is rebuilt the state is moved into a second set of arrays.
-// gte_get_state extracts env-indexed views for the host on demand.
-struct StateArrays {
-  int32_t *idx, *step, *pos, *dsi, *start, *episode, *needs_reset, *eps_on_ds, *n_picks, *q_head,
-      *lo_n;
-  double *asset, *fiat, *ia, *ifi, *pv, *realpos;
-  // prices the NEXT step needs, fetched by this step off its critical path
-  double *close_cur;   // close[idx]
-  double *close_next;  // close[idx + 1] (close[idx] at the last row)
+// Per-env state record: ONE 128-byte line per environment, so that an env reached
+// through the L2-affinity permutation costs one line in and one line out (as a
+// struct of arrays the same gather touched 13 sectors per env and cancelled the
+// gain).  gte_get_state extracts struct-of-arrays views for the host on demand.
+struct alignas(128) EnvRec {
+  int32_t idx, step, pos, dsi, start, episode, needs_reset, eps_on_ds;  // 32 B
+  int32_t n_picks, q_head, lo_n, pad0;                                  // 16 B
+  double asset, fiat, ia, ifi, pv, realpos;                             // 48 B
+  int32_t pad1[8];                                                      // -> 128 B
 };
+static_assert(sizeof(EnvRec) == 128, "EnvRec must be one 128-byte line");
 
 // Everything a launch needs; passed by value as the kernel argument.
 struct Params {
@@ -49,12 +46,10 @@ struct Params {
   uint64_t seed;
   int64_t env_id_base;
   // --- resident tables
-  DatasetDesc ds0;        // copy of ds[0]: with one dataset no descriptor load is needed
   const DatasetDesc* ds;
   const double* positions;  // f64 [P]
-  // --- per-env state, slot-indexed (slot == env id while perm is null)
-  StateArrays st;
-  const int32_t* slot_of_env;  // env id -> slot, or null = identity
+  // --- per-env state, one 128-byte record per env
+  EnvRec* rec;
   float* ring;  // f32 [N, depth, nd]
   // --- pending limit orders (null until the first gte_add_limit_orders)
   int32_t* lo_pos;      // i32 [N, P] target position index, insertion order

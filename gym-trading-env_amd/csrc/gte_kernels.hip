@@ -10,8 +10,8 @@
 //            limit-order fills -> update_interest -> valorisation ->
 //            done/truncated -> reward), auto-reset with Philox or injected
 //            draws, wave-level compaction of the terminal mask (__ballot +
-//            popcount prefix, one atomic per wave).  The per-env state is a
-//            struct of arrays stored in processing (slot) order: coalesced.
+//            popcount prefix, one atomic per wave).  The per-env state is one
+//            128-byte record, reached through the L2-affinity permutation.
 //   gather   _get_obs (:152-160): the window of env e is ONE contiguous block of
 //            W*F_obs floats of the row-major feature table, moved with 16-byte
 //            loads / non-temporal stores (1 KiB per wave instruction) and patched
@@ -24,9 +24,8 @@
 //           gte_kernel<MODE,...>     classic order (phase A, barrier, gather):
 //                                    resets, dyn_persist, windows=None, odd shapes;
 //           gte_affinity_*           counting sort of the envs by table region
-//                                    (processing order, speed only); moves the
-//                                    slot-ordered state along;
-//           gte_add_orders / gte_extract_state: small helpers.
+//                                    (processing order, speed only);
+//           gte_add_orders / gte_extract_state / gte_rewind_queue: small helpers.
 //
 // The path is HBM-bound (no contraction, so no MFMA): >= 97 % of its bytes are the
 // window gather + observation store.  See DESIGN.md for roofline and measurements.
@@ -41,35 +40,30 @@ enum { MODE_STEP = 0, MODE_RESET = 1 };
 struct EnvRegs {
   int32_t idx, step, pos, dsi, start, episode, needs_reset, eps_on_ds, n_picks, q_head, lo_n;
   Portfolio q;
-  double pv, realpos, close_cur, close_next;
+  double pv, realpos;
 };
 
-// descriptor of dataset d: from the kernel arguments when there is only one
-__device__ inline DatasetDesc dataset(const Params& p, int d) {
-  if (p.D == 1) return p.ds0;  // wave-uniform
-  return p.ds[d];
+__device__ inline void load_state(const Params& p, int e, EnvRegs& s) {
+  const EnvRec r = p.rec[e];  // 128-byte aligned record: six 16-byte loads
+  s.idx = r.idx; s.step = r.step; s.pos = r.pos; s.dsi = r.dsi; s.start = r.start;
+  s.episode = r.episode; s.needs_reset = r.needs_reset; s.eps_on_ds = r.eps_on_ds;
+  s.n_picks = r.n_picks; s.q_head = r.q_head; s.lo_n = r.lo_n;
+  s.q.asset = r.asset; s.q.fiat = r.fiat; s.q.ia = r.ia; s.q.ifi = r.ifi;
+  s.pv = r.pv; s.realpos = r.realpos;
 }
 
-__device__ inline void load_state(const Params& p, int slot, EnvRegs& s) {
-  const StateArrays& a = p.st;
-  s.idx = a.idx[slot]; s.step = a.step[slot]; s.pos = a.pos[slot]; s.dsi = a.dsi[slot];
-  s.start = a.start[slot]; s.episode = a.episode[slot]; s.needs_reset = a.needs_reset[slot];
-  s.eps_on_ds = a.eps_on_ds[slot]; s.n_picks = a.n_picks[slot]; s.q_head = a.q_head[slot];
-  s.lo_n = a.lo_n[slot];
-  s.q.asset = a.asset[slot]; s.q.fiat = a.fiat[slot]; s.q.ia = a.ia[slot]; s.q.ifi = a.ifi[slot];
-  s.pv = a.pv[slot]; s.realpos = a.realpos[slot];
-  s.close_cur = a.close_cur[slot]; s.close_next = a.close_next[slot];
-}
-
-__device__ inline void store_state(const Params& p, int slot, const EnvRegs& s) {
-  const StateArrays& a = p.st;
-  a.idx[slot] = s.idx; a.step[slot] = s.step; a.pos[slot] = s.pos; a.dsi[slot] = s.dsi;
-  a.start[slot] = s.start; a.episode[slot] = s.episode; a.needs_reset[slot] = s.needs_reset;
-  a.eps_on_ds[slot] = s.eps_on_ds; a.n_picks[slot] = s.n_picks; a.q_head[slot] = s.q_head;
-  a.lo_n[slot] = s.lo_n;
-  a.asset[slot] = s.q.asset; a.fiat[slot] = s.q.fiat; a.ia[slot] = s.q.ia; a.ifi[slot] = s.q.ifi;
-  a.pv[slot] = s.pv; a.realpos[slot] = s.realpos;
-  a.close_cur[slot] = s.close_cur; a.close_next[slot] = s.close_next;
+__device__ inline void store_state(const Params& p, int e, const EnvRegs& s) {
+  EnvRec r;
+  r.idx = s.idx; r.step = s.step; r.pos = s.pos; r.dsi = s.dsi; r.start = s.start;
+  r.episode = s.episode; r.needs_reset = s.needs_reset; r.eps_on_ds = s.eps_on_ds;
+  r.n_picks = s.n_picks; r.q_head = s.q_head; r.lo_n = s.lo_n; r.pad0 = 0;
+  r.asset = s.q.asset; r.fiat = s.q.fiat; r.ia = s.q.ia; r.ifi = s.q.ifi;
+  r.pv = s.pv; r.realpos = s.realpos;
+  // only the 96 live bytes are written
+  uint4* dst = reinterpret_cast<uint4*>(&p.rec[e]);
+  const uint4* src = reinterpret_cast<const uint4*>(&r);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dst[i] = src[i];
 }
 
 // MultiDatasetTradingEnv.next_dataset, environments.py:380-391
@@ -98,7 +92,7 @@ __device__ inline void do_reset(const Params& p, int e, int32_t inj_idx, int32_t
   if (pi < 0) pi = (inj_pos >= 0) ? inj_pos : bounded(r[0], p.P);
   s.pos = pi;
   int32_t idx = p.has_window ? p.W - 1 : 0;  // :171-172
-  const DatasetDesc d = dataset(p, s.dsi);
+  const DatasetDesc d = p.ds[s.dsi];
   if (p.max_dur > 0) {  // :173-177 randint(low=idx, high=T - max_dur - idx)
     const int32_t low = idx;
     const int32_t high = (int32_t)d.T - p.max_dur - idx;
@@ -108,8 +102,6 @@ __device__ inline void do_reset(const Params& p, int e, int32_t inj_idx, int32_t
   s.start = idx;
   const double position = p.positions[pi];  // TargetPortfolio, portfolio.py:59-66
   const double price = d.close[idx];
-  s.close_cur = price;
-  s.close_next = d.close[idx + 1 < (int32_t)d.T ? idx + 1 : idx];
   s.q.asset = position * p.V0 / price;
   s.q.fiat = (1.0 - position) * p.V0;
   s.q.ia = 0.0;
@@ -162,11 +154,10 @@ __global__ void gte_add_orders_kernel(const Params p, const int32_t* pos_index,
   const int32_t pi = pos_index[e];
   if (pi < 0) return;
   int32_t* lp = p.lo_pos + (int64_t)e * p.P;
-  const int slot = p.slot_of_env ? p.slot_of_env[e] : e;
-  const int n = p.st.lo_n[slot];
+  const int n = p.rec[e].lo_n;
   int j = 0;
   while (j < n && p.positions[lp[j]] != p.positions[pi]) ++j;
-  if (j == n) p.st.lo_n[slot] = n + 1;  // n < P: at most one order per distinct position value
+  if (j == n) p.rec[e].lo_n = n + 1;  // n < P: at most one order per distinct position value
   lp[j] = pi;
   p.lo_limit[(int64_t)e * p.P + j] = limit[e];
   p.lo_persist[(int64_t)e * p.P + j] = persistent ? persistent[e] : 0;
@@ -202,7 +193,7 @@ __device__ inline void make_job(const Params& p, int e, const EnvRegs& s, bool f
     job.cur[i] = v;
   }
   const int32_t first = s.idx - p.W + 1;  // first row of the window (:159)
-  job.src = dataset(p, s.dsi).feat + (int64_t)first * p.Fobs;
+  job.src = p.ds[s.dsi].feat + (int64_t)first * p.Fobs;
   job.slot0 = p.persist ? first : (s.idx + 1) % p.W;
   int32_t nz;
   if (fresh) nz = p.W - 1;            // brand-new _obs_array: only the current row is set
@@ -233,10 +224,10 @@ __device__ inline Prediction predict_job(const Params& p, int32_t idx, int32_t d
   int32_t idx_new = idx + 1;
   if (needs_reset) {
     if (p.autoreset == GTE_AUTORESET_NEXT_STEP) q.ok = false;   // will be reset
-    else if (idx >= (int32_t)dataset(p, dsi).T - 1) idx_new = idx;   // frozen
+    else if (idx >= (int32_t)p.ds[dsi].T - 1) idx_new = idx;   // frozen
   }
   const int32_t first = idx_new - p.W + 1;
-  q.src = dataset(p, dsi).feat + (int64_t)first * p.Fobs;
+  q.src = p.ds[dsi].feat + (int64_t)first * p.Fobs;
   q.slot0 = (idx_new + 1) % p.W;
   const int32_t nz = start - first;
   q.n_zero = nz < 0 ? 0 : (nz > p.W - 1 ? p.W - 1 : nz);
@@ -251,7 +242,7 @@ struct OldState {  // what phase A started from (for the prediction check)
 };
 
 template <int MODE>
-__device__ inline void phase_a(const Params& p, int e, int slot, bool active, int lane, ObsJob& job,
+__device__ inline void phase_a(const Params& p, int e, bool active, int lane, ObsJob& job,
                                OldState* old = nullptr, FinalJob* fin = nullptr) {
   if (fin) fin->flags = 0;
   job.src = nullptr; job.slot0 = 0; job.n_zero = 0; job.idx = 0; job.flags = 0;
@@ -262,14 +253,14 @@ __device__ inline void phase_a(const Params& p, int e, int slot, bool active, in
   if (MODE == MODE_RESET) {
     if (active && (p.mask == nullptr || p.mask[e] != 0)) {
       EnvRegs s;
-      load_state(p, slot, s);
+      load_state(p, e, s);
       bool fresh = false;
       const int32_t ii = p.inj_idx ? p.inj_idx[e] : -1;
       const int32_t ip = p.inj_pos ? p.inj_pos[e] : -1;
       const int32_t id = p.inj_ds ? p.inj_ds[e] : -1;
       if (p.D > 1 && s.n_picks == 0) next_dataset(p, e, id, s, fresh);  // ctor pick, :378
       do_reset(p, e, ii, ip, id, s, fresh);
-      store_state(p, slot, s);
+      store_state(p, e, s);
       p.reward[e] = 0.0f; p.reward64[e] = 0.0;
       p.terminated[e] = 0; p.truncated[e] = 0;
       make_job(p, e, s, fresh, job);
@@ -280,7 +271,7 @@ __device__ inline void phase_a(const Params& p, int e, int slot, bool active, in
   // MODE_STEP — TradingEnv.step, environments.py:233-272
   if (active) {
     EnvRegs s;
-    load_state(p, slot, s);
+    load_state(p, e, s);
     if (old) { old->idx = s.idx; old->dsi = s.dsi; old->start = s.start; old->needs_reset = s.needs_reset; }
     int32_t action = p.actions[e];
     // positions[position_index] raises IndexError in the reference (:234); a device-side
@@ -296,7 +287,7 @@ __device__ inline void phase_a(const Params& p, int e, int slot, bool active, in
         p.reward[e] = 0.0f; p.reward64[e] = 0.0;
         p.terminated[e] = 0; p.truncated[e] = 0;
         stepped = false;
-      } else if (s.idx >= (int32_t)dataset(p, s.dsi).T - 1) {
+      } else if (s.idx >= (int32_t)p.ds[s.dsi].T - 1) {
         // no auto-reset and no row left: the reference raises IndexError (:239);
         // the batch leaves such an env frozen, flags still raised
         p.reward[e] = 0.0f; p.reward64[e] = 0.0;
@@ -305,23 +296,18 @@ __device__ inline void phase_a(const Params& p, int e, int slot, bool active, in
       }
     }
     if (stepped) {
-      const DatasetDesc d = dataset(p, s.dsi);
-      // close[idx + 2] for the NEXT step: issued now, consumed only by the record store
-      const int32_t i2 = s.idx + 2 < (int32_t)d.T ? s.idx + 2 : (int32_t)d.T - 1;
-      const double close_after = d.close[i2];
+      const DatasetDesc d = p.ds[s.dsi];
       if (action >= 0) {  // :234 -> :213-215: trade only when the position VALUE differs
         const double position = p.positions[action];
         if (position != p.positions[s.pos]) {
-          trade_to_position(s.q, position, s.close_cur, p.fees);  // :204-209, price = close[idx]
+          trade_to_position(s.q, position, d.close[s.idx], p.fees);  // :204-209
           s.pos = action;                                             // :210
         }
       }
       s.idx += 1;   // :235
       s.step += 1;  // :236
       if (p.lo_pos) fill_limit_orders(p, e, d, s);  // :238
-      const double price = s.close_next;  // :239 close[idx], kept in the record
-      s.close_cur = price;
-      s.close_next = close_after;
+      const double price = d.close[s.idx];  // :239
       s.q.ia = pymax0(-s.q.asset) * p.rate;   // update_interest, portfolio.py:44-46
       s.q.ifi = pymax0(-s.q.fiat) * p.rate;
       const double pv = valorisation(s.q, price);  // :241
@@ -360,7 +346,7 @@ __device__ inline void phase_a(const Params& p, int e, int slot, bool active, in
         }
       }
     }
-    store_state(p, slot, s);
+    store_state(p, e, s);
     make_job(p, e, s, fresh, job);
   }
 
@@ -716,11 +702,10 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
     const int s = COOP ? lane : wib * p.epw + lane;  // LDS slot = env within the workgroup
     const bool owns = COOP ? (lane < EPB) : (lane < p.epw);
     const bool active = owns && s < n_wg;
-    const int slot = wg_first + s;
-    const int e = active ? (p.perm ? p.perm[slot] : slot) : 0;
+    const int e = active ? (p.perm ? p.perm[wg_first + s] : wg_first + s) : 0;
     ObsJob job;
     FinalJob fin;
-    phase_a<MODE>(p, e, slot, active, lane, job, nullptr, p.final_obs ? &fin : nullptr);
+    phase_a<MODE>(p, e, active, lane, job, nullptr, p.final_obs ? &fin : nullptr);
     if (owns) publish_job(L, s, job);  // slots past the last env get flags = 0
     if (owns && p.final_obs) L.fin[s] = fin;
   }
@@ -896,11 +881,10 @@ __global__ __launch_bounds__(256) void gte_step_overlap_kernel(const Params p, c
     // ---------------- wave 0: phase A for the whole workgroup
     const int s = lane;
     const bool active = s < n_wg;
-    const int slot = wg_first + s;
-    const int e = active ? (p.perm ? p.perm[slot] : slot) : 0;
+    const int e = active ? (p.perm ? p.perm[wg_first + s] : wg_first + s) : 0;
     ObsJob job;
     OldState old = {0, 0, 0, 0};
-    phase_a<MODE_STEP>(p, e, slot, active, lane, job, &old);
+    phase_a<MODE_STEP>(p, e, active, lane, job, &old);
     L.job[s].src = (uint64_t)job.src;
     L.job[s].meta = pack_meta(job.flags, job.n_zero, job.slot0);
 #pragma unroll
@@ -917,9 +901,8 @@ __global__ __launch_bounds__(256) void gte_step_overlap_kernel(const Params p, c
   } else if (n_env > 0 && !(p.debug & 1)) {
     // ---------------- waves 1..3: rows 0..W-2 of the predicted windows, right away
     if (lane < n_env) {
-      const int slot = wg_first + s_first + lane;  // the state is stored in slot order
-      const Prediction q = predict_job(p, p.st.idx[slot], p.st.dsi[slot], p.st.start[slot],
-                                       p.st.needs_reset[slot]);
+      const EnvRec* r = &p.rec[L.job[s_first + lane].env];
+      const Prediction q = predict_job(p, r->idx, r->dsi, r->start, r->needs_reset);
       L.pjob[s_first + lane].src = (uint64_t)q.src;
       L.pjob[s_first + lane].meta = pack_meta(q.ok ? 1 : 0, q.n_zero, q.slot0);
     }
@@ -971,18 +954,14 @@ hipError_t launch_step_overlap(const Params& p, int vec, int nt, hipStream_t str
 // env is a counting sort of the envs by (dataset, row bucket), laid out so that the
 // r-th env in sorted order goes to the r-th slot in XCD-major order (slot_of_rank,
 // built on the host).  Results do not depend on the permutation; only speed does.
-__device__ inline int affinity_bin(const Params& p, int slot, int n_bins_per_ds) {
-  const int d = p.st.dsi[slot];
-  const int64_t T = dataset(p, d).T;
-  int b = (int)(((int64_t)p.st.idx[slot] * n_bins_per_ds) / T);
-  b = b < 0 ? 0 : (b >= n_bins_per_ds ? n_bins_per_ds - 1 : b);
-  return d * n_bins_per_ds + b;
-}
-
 __global__ void gte_affinity_hist_kernel(const Params p, int32_t* hist, int n_bins_per_ds) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;  // current slot
-  if (j >= p.N) return;
-  atomicAdd(&hist[affinity_bin(p, j, n_bins_per_ds)], 1);
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.N) return;
+  const int d = p.rec[e].dsi;
+  const int64_t T = p.ds[d].T;
+  int b = (int)(((int64_t)p.rec[e].idx * n_bins_per_ds) / T);
+  b = b < 0 ? 0 : (b >= n_bins_per_ds ? n_bins_per_ds - 1 : b);
+  atomicAdd(&hist[d * n_bins_per_ds + b], 1);
 }
 
 // exclusive scan of `hist` (n_bins <= 1024 * per_thread) by one workgroup
@@ -1009,31 +988,21 @@ __global__ __launch_bounds__(1024) void gte_affinity_scan_kernel(int32_t* hist, 
   }
 }
 
-// every env moves from its current slot j to its new slot q, state included
-__global__ void gte_affinity_scatter_kernel(const Params p, const StateArrays n, int32_t* cursor,
-                                            int n_bins_per_ds, const int32_t* slot_of_rank,
-                                            int32_t* perm_new, int32_t* slot_of_env) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= p.N) return;
-  const int e = p.perm ? p.perm[j] : j;
-  const int rank = atomicAdd(&cursor[affinity_bin(p, j, n_bins_per_ds)], 1);
-  const int q = slot_of_rank[rank];
-  perm_new[q] = e;
-  slot_of_env[e] = q;
-  const StateArrays& o = p.st;
-  n.idx[q] = o.idx[j]; n.step[q] = o.step[j]; n.pos[q] = o.pos[j]; n.dsi[q] = o.dsi[j];
-  n.start[q] = o.start[j]; n.episode[q] = o.episode[j]; n.needs_reset[q] = o.needs_reset[j];
-  n.eps_on_ds[q] = o.eps_on_ds[j]; n.n_picks[q] = o.n_picks[j]; n.q_head[q] = o.q_head[j];
-  n.lo_n[q] = o.lo_n[j];
-  n.asset[q] = o.asset[j]; n.fiat[q] = o.fiat[j]; n.ia[q] = o.ia[j]; n.ifi[q] = o.ifi[j];
-  n.pv[q] = o.pv[j]; n.realpos[q] = o.realpos[j];
-  n.close_cur[q] = o.close_cur[j]; n.close_next[q] = o.close_next[j];
+__global__ void gte_affinity_scatter_kernel(const Params p, int32_t* cursor, int n_bins_per_ds,
+                                            const int32_t* slot_of_rank, int32_t* perm_out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.N) return;
+  const int d = p.rec[e].dsi;
+  const int64_t T = p.ds[d].T;
+  int b = (int)(((int64_t)p.rec[e].idx * n_bins_per_ds) / T);
+  b = b < 0 ? 0 : (b >= n_bins_per_ds ? n_bins_per_ds - 1 : b);
+  const int rank = atomicAdd(&cursor[d * n_bins_per_ds + b], 1);
+  perm_out[slot_of_rank[rank]] = e;
 }
 
-// p: current state/perm (source); nst/perm_new/slot_of_env: destination
-hipError_t launch_affinity_rebuild(const Params& p, const StateArrays& nst, int32_t* bins,
-                                   int n_bins_per_ds, const int32_t* slot_of_rank,
-                                   int32_t* perm_new, int32_t* slot_of_env, hipStream_t stream) {
+hipError_t launch_affinity_rebuild(const Params& p, int32_t* bins, int n_bins_per_ds,
+                                   const int32_t* slot_of_rank, int32_t* perm_out,
+                                   hipStream_t stream) {
   const int n_bins = p.D * n_bins_per_ds;
   hipError_t e = hipMemsetAsync(bins, 0, sizeof(int32_t) * n_bins, stream);
   if (e != hipSuccess) return e;
@@ -1041,8 +1010,8 @@ hipError_t launch_affinity_rebuild(const Params& p, const StateArrays& nst, int3
   hipLaunchKernelGGL(gte_affinity_hist_kernel, dim3(blocks), dim3(256), 0, stream, p, bins,
                      n_bins_per_ds);
   hipLaunchKernelGGL(gte_affinity_scan_kernel, dim3(1), dim3(1024), 0, stream, bins, n_bins);
-  hipLaunchKernelGGL(gte_affinity_scatter_kernel, dim3(blocks), dim3(256), 0, stream, p, nst, bins,
-                     n_bins_per_ds, slot_of_rank, perm_new, slot_of_env);
+  hipLaunchKernelGGL(gte_affinity_scatter_kernel, dim3(blocks), dim3(256), 0, stream, p, bins,
+                     n_bins_per_ds, slot_of_rank, perm_out);
   return hipGetLastError();
 }
 
@@ -1053,19 +1022,28 @@ struct StateSoA {
   double *asset, *fiat, *ia, *ifi, *pv, *realpos;
 };
 
-__global__ void gte_extract_state_kernel(const Params p, StateSoA o) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;  // slot
-  if (j >= p.N) return;
-  const int e = p.perm ? p.perm[j] : j;
-  const StateArrays& a = p.st;
-  o.idx[e] = a.idx[j]; o.step[e] = a.step[j]; o.pos[e] = a.pos[j]; o.dsi[e] = a.dsi[j];
-  o.start[e] = a.start[j]; o.episode[e] = a.episode[j]; o.needs_reset[e] = a.needs_reset[j];
-  o.asset[e] = a.asset[j]; o.fiat[e] = a.fiat[j]; o.ia[e] = a.ia[j]; o.ifi[e] = a.ifi[j];
-  o.pv[e] = a.pv[j]; o.realpos[e] = a.realpos[j];
+__global__ void gte_extract_state_kernel(const EnvRec* rec, int n, StateSoA o) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const EnvRec r = rec[e];
+  o.idx[e] = r.idx; o.step[e] = r.step; o.pos[e] = r.pos; o.dsi[e] = r.dsi;
+  o.start[e] = r.start; o.episode[e] = r.episode; o.needs_reset[e] = r.needs_reset;
+  o.asset[e] = r.asset; o.fiat[e] = r.fiat; o.ia[e] = r.ia; o.ifi[e] = r.ifi;
+  o.pv[e] = r.pv; o.realpos[e] = r.realpos;
 }
 
-hipError_t launch_extract_state(const Params& p, const StateSoA& o, hipStream_t stream) {
-  hipLaunchKernelGGL(gte_extract_state_kernel, dim3((p.N + 255) / 256), dim3(256), 0, stream, p, o);
+hipError_t launch_extract_state(const EnvRec* rec, int n, const StateSoA& o, hipStream_t stream) {
+  hipLaunchKernelGGL(gte_extract_state_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, rec, n, o);
+  return hipGetLastError();
+}
+
+__global__ void gte_rewind_queue_kernel(EnvRec* rec, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) rec[e].q_head = 0;
+}
+
+hipError_t launch_rewind_queue(EnvRec* rec, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(gte_rewind_queue_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, rec, n);
   return hipGetLastError();
 }
 
