@@ -75,6 +75,8 @@ class GteConfig(C.Structure):
         ("kernel_variant", C.c_int32),
         ("debug_flags", C.c_int32),
         ("affinity_period", C.c_int32),
+        ("log_steps", C.c_int32),
+        ("reserved2", C.c_int32),
         ("final_obs", C.c_int32),
     ]
 
@@ -138,6 +140,8 @@ SYMBOLS = {
                                                C.c_void_p, C.c_void_p]),
     "gte_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "gte_add_limit_orders": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gte_get_log": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gte_read_log": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 8 + [_P(C.c_int32)]),
     "gte_get_outputs": (C.c_int, [C.c_void_p, _P(GteOutputs)]),
     "gte_get_state": (C.c_int, [C.c_void_p, _P(GteStateView)]),
     "gte_bind_outputs": (C.c_int, [C.c_void_p, _P(GteOutputs)]),

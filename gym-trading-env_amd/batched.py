@@ -121,6 +121,10 @@ class BatchedTradingEnv(_VectorEnvBase):
 :param final_obs: with ``autoreset="same_step"``: keep the terminal observation of
         every env that ends (Gymnasium's ``final_observation`` / SB3's
         ``terminal_observation``); read it with :meth:`final_observations`.
+:param log_steps: L > 0 keeps the last L steps of every env in a device trajectory
+        log; :meth:`history` turns one env's episode into a `History` (the object the
+        reference hands to custom reward / metric functions) and `add_metric` functions
+        are evaluated by :meth:`episode_metrics`.
     :param dyn_persist: keep the per-env dynamic-feature column across episodes like
         the reference's in-place write into `_obs_array` (:153-154); costs
         N*T*n_dyn*4 bytes of HBM.
@@ -137,7 +141,7 @@ class BatchedTradingEnv(_VectorEnvBase):
                  episodes_between_dataset_switch=1, dyn_persist=False, seed=0,
                  env_id_base=0, device=0, output="torch", envs_per_wave=0,
                  nontemporal_obs=2, kernel_variant=0, library_path=None, debug_flags=0,
-                 affinity_period=0, final_obs=False):
+                 affinity_period=0, final_obs=False, log_steps=0):
         assert render_mode is None or render_mode in self.metadata["render_modes"]
         if output not in ("torch", "numpy"):
             raise ValueError("output must be 'torch' or 'numpy'")
@@ -173,7 +177,8 @@ class BatchedTradingEnv(_VectorEnvBase):
             dyn_persist=dyn_persist, seed=seed, env_id_base=env_id_base, device=device,
             envs_per_wave=envs_per_wave, nontemporal_obs=nontemporal_obs,
             kernel_variant=kernel_variant, debug_flags=debug_flags,
-            affinity_period=affinity_period, final_obs=final_obs)
+            affinity_period=affinity_period, final_obs=final_obs, log_steps=log_steps)
+        self.log_metrics = []
         _abi.check(self._lib, self._lib.gte_create(C.byref(self.cfg), C.byref(self._h)))
 
         self.n_obs = first.n_static + n_dyn
@@ -307,6 +312,50 @@ class BatchedTradingEnv(_VectorEnvBase):
             return ids, self._t["final_obs"][idx]
         return ids, self.read_output("final_obs")[ids]
 
+    # -- trajectory log ------------------------------------------------------------------
+    def add_metric(self, name, function):
+        """`TradingEnv.add_metric` (environments.py:274-278): `function(history)` is evaluated
+        for every finished env by :meth:`episode_metrics` (needs ``log_steps``)."""
+        if not self.cfg.log_steps:
+            raise ValueError("add_metric needs log_steps > 0 (the History comes from the device log)")
+        self.log_metrics.append({"name": name, "function": function})
+
+    def history(self, env_id: int):
+        """The current (or just finished) episode of one env as a `History` with the
+        reference's columns (environments.py:186-197, 253-264), rebuilt from the device
+        trajectory log.  Episodes longer than ``log_steps`` are truncated at the front."""
+        from .history import History
+        L = int(self.cfg.log_steps)
+        if not L:
+            raise ValueError("constructed with log_steps=0")
+        bufs = {"idx": np.empty(L, np.int32), "step": np.empty(L, np.int32),
+                "pos": np.empty(L, np.int32), "ds": np.empty(L, np.int32),
+                "pv": np.empty(L, np.float64), "rp": np.empty(L, np.float64),
+                "rew": np.empty(L, np.float64), "flags": np.empty(L, np.uint8)}
+        n = C.c_int32()
+        _abi.check(self._lib, self._lib.gte_read_log(
+            self._h, int(env_id), L, *(b.ctypes.data for b in bufs.values()), C.byref(n)))
+        n = n.value
+        step = bufs["step"][:n]
+        # the episode = the last run of rows whose step counts 0, 1, 2, ...
+        start = n - 1
+        while start > 0 and step[start - 1] == step[start] - 1:
+            start -= 1
+        h = History(max_size=max(n - start, 1))
+        positions = self.positions
+        for k in range(start, n):
+            d, t, pi = int(bufs["ds"][k]), int(bufs["idx"][k]), int(bufs["pos"][k])
+            ds = self.datasets[d]
+            data = ({c: ds.info_array[t, j] for j, c in enumerate(ds.info_columns)}
+                    if ds.info_array is not None else {"close": ds.close[t]})
+            row = dict(idx=t, step=int(step[k]),
+                       date=ds.index[t] if ds.index is not None else t,
+                       position_index=pi, position=positions[pi],
+                       real_position=float(bufs["rp"][k]), data=data,
+                       portfolio_valuation=float(bufs["pv"][k]), reward=float(bufs["rew"][k]))
+            (h.set if k == start else h.add)(**row)
+        return h
+
     def episode_metrics(self, env_ids=None) -> dict:
         """Episode-end metrics of `calculate_metrics` (environments.py:279-286) for the envs
         whose episode just ended (default: `terminal_ids()`), from the device state:
@@ -321,10 +370,15 @@ class BatchedTradingEnv(_VectorEnvBase):
         close_0 = np.array([self.datasets[d].close[i] for d, i in zip(ds, start)], dtype=np.float64)
         market = close_now / close_0 - 1 if len(ids) else np.zeros(0)
         portfolio = pv / self.cfg.portfolio_initial_value - 1
-        return {"env_ids": ids, "market_return": market, "portfolio_return": portfolio,
-                "episode_length": self.state("step")[ids] + 1,
-                "Market Return": [f"{100 * m:5.2f}%" for m in market],
-                "Portfolio Return": [f"{100 * r:5.2f}%" for r in portfolio]}
+        out = {"env_ids": ids, "market_return": market, "portfolio_return": portfolio,
+               "episode_length": self.state("step")[ids] + 1,
+               "Market Return": [f"{100 * m:5.2f}%" for m in market],
+               "Portfolio Return": [f"{100 * r:5.2f}%" for r in portfolio]}
+        if self.log_metrics:  # custom metrics over each finished env's History (:285-286)
+            hists = [self.history(int(e)) for e in ids]
+            for metric in self.log_metrics:
+                out[metric["name"]] = [metric["function"](h) for h in hists]
+        return out
 
     def _results(self):
         if self.output == "torch":

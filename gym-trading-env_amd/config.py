@@ -85,7 +85,7 @@ def make_config(*, n_envs: int, n_static: int, n_datasets: int = 1,
                 device: int = 0, envs_per_wave: int = 0,
                 nontemporal_obs: int = 2, kernel_variant: int = 0,
                 debug_flags: int = 0, affinity_period: int = 0,
-                final_obs: bool = False) -> _abi.GteConfig:
+                final_obs: bool = False, log_steps: int = 0) -> _abi.GteConfig:
     positions = list(positions)
     if not 0 < len(positions) <= _abi.GTE_MAX_POSITIONS:
         raise ValueError(f"1..{_abi.GTE_MAX_POSITIONS} positions supported")
@@ -144,4 +144,7 @@ def make_config(*, n_envs: int, n_static: int, n_datasets: int = 1,
     if final_obs and _AUTORESET_BY_NAME[autoreset] != _abi.AUTORESET_SAME_STEP:
         raise ValueError("final_obs needs autoreset='same_step'")
     cfg.final_obs = int(bool(final_obs))
+    if log_steps < 0:
+        raise ValueError("log_steps must be >= 0")
+    cfg.log_steps = int(log_steps)
     return cfg

@@ -31,6 +31,14 @@ struct StateSoA {
 };
 hipError_t launch_extract_state(const EnvRec* rec, int n, const StateSoA& o, hipStream_t stream);
 hipError_t launch_rewind_queue(EnvRec* rec, int n, hipStream_t stream);
+struct LogArrays {
+  int32_t *idx, *step, *pos, *dsi;
+  double *pv, *realpos, *reward;
+  uint8_t* flags;
+};
+hipError_t launch_log(const EnvRec* rec, const double* reward64, const uint8_t* term,
+                      const uint8_t* trunc, int n, int64_t row_base, const LogArrays& o,
+                      hipStream_t stream);
 hipError_t launch_affinity_rebuild(const Params& p, int32_t* bins, int n_bins_per_ds,
                                    const int32_t* slot_of_rank, int32_t* perm_out,
                                    hipStream_t stream);
@@ -96,6 +104,8 @@ struct gte_env {
   int32_t* d_slot_of_rank = nullptr;
   int32_t* d_bins = nullptr;
   gte::StateSoA soa = {};  // host-facing struct-of-arrays mirrors (gte_get_state)
+  gte::LogArrays log = {}; // device trajectory log (cfg.log_steps rows per env)
+  int64_t log_rows = 0;
 };
 
 template <typename T>
@@ -151,6 +161,7 @@ static int validate(const gte_config* c) {
     return fail(GTE_ERR_INVALID, "episodes_between_dataset_switch must be >= 1");
   if (c->nontemporal_obs < 0 || c->nontemporal_obs > 2)
     return fail(GTE_ERR_INVALID, "nontemporal_obs must be 0 (plain), 1 (nt) or 2 (sc1)");
+  if (c->log_steps < 0) return fail(GTE_ERR_INVALID, "log_steps must be >= 0");
   if (c->final_obs && c->autoreset != GTE_AUTORESET_SAME_STEP)
     return fail(GTE_ERR_INVALID, "final_obs needs autoreset = same-step");
   if (c->envs_per_wave != 0 &&
@@ -248,6 +259,13 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   chk(dev_alloc(E, &E->d_actions, N)); chk(dev_alloc(E, &E->d_mask, N));
   chk(dev_alloc(E, &E->d_inj_idx, N)); chk(dev_alloc(E, &E->d_inj_pos, N));
   chk(dev_alloc(E, &E->d_inj_ds, N));
+  if (cfg->log_steps > 0) {
+    const size_t LN = (size_t)cfg->log_steps * N;
+    chk(dev_alloc(E, &E->log.idx, LN)); chk(dev_alloc(E, &E->log.step, LN));
+    chk(dev_alloc(E, &E->log.pos, LN)); chk(dev_alloc(E, &E->log.dsi, LN));
+    chk(dev_alloc(E, &E->log.pv, LN)); chk(dev_alloc(E, &E->log.realpos, LN));
+    chk(dev_alloc(E, &E->log.reward, LN)); chk(dev_alloc(E, &E->log.flags, LN));
+  }
   double* d_pos = nullptr;
   chk(dev_alloc(E, &d_pos, GTE_MAX_POSITIONS));
   chk(dev_alloc(E, &E->d_ds, (size_t)p.D));
@@ -419,6 +437,16 @@ static int check_injection(const gte_env* E, size_t count, const int32_t* idx, c
   return GTE_OK;
 }
 
+// append one trajectory row per env (after a reset or a step)
+static int append_log(gte_env* E) {
+  if (E->cfg.log_steps <= 0) return GTE_OK;
+  const Params& p = E->p;
+  const int64_t row_base = (E->log_rows % E->cfg.log_steps) * (int64_t)p.N;
+  HIPCHK(gte::launch_log(p.rec, p.reward64, p.terminated, p.truncated, p.N, row_base, E->log, E->stream));
+  E->log_rows += 1;
+  return GTE_OK;
+}
+
 static int stage(gte_env* E, void* dst, const void* src, size_t bytes) {
   HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, E->stream));
   return GTE_OK;
@@ -443,6 +471,7 @@ int gte_reset(gte_env* E, const uint8_t* mask, const int32_t* inj_idx,
   p.term_count_next = E->term_base + 1;
   HIPCHK(gte::launch_reset(p, E->vec, E->cfg.nontemporal_obs, E->coop, E->stage, E->blocks,
                            E->threads, E->stream));
+  TRY(append_log(E));
   if (E->affinity_period > 0) {  // new start rows: re-sort the processing order
     HIPCHK(gte::launch_affinity_rebuild(E->p, E->d_bins, E->n_bins_per_ds, E->d_slot_of_rank,
                                         E->d_perm, E->stream));
@@ -515,6 +544,7 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
   else
     HIPCHK(gte::launch_step(p, E->vec, E->cfg.nontemporal_obs, E->coop, E->stage, E->blocks,
                             E->threads, E->stream));
+  TRY(append_log(E));
   return GTE_OK;
 }
 
@@ -546,6 +576,49 @@ int gte_add_limit_orders(gte_env* E, const int32_t* pos_index, const double* lim
   HIPCHK(gte::launch_add_orders(p, E->d_inj_pos, E->d_lo_limit_in,
                                 persistent ? E->d_lo_persist_in : nullptr, E->stream));
   HIPCHK(hipStreamSynchronize(E->stream));  // host arrays and staging buffers are free again
+  return GTE_OK;
+}
+
+int gte_get_log(gte_env* E, gte_log_view* out) {
+  if (!E || !out) return fail(GTE_ERR_INVALID, "NULL argument");
+  if (E->cfg.log_steps <= 0) return fail(GTE_ERR_STATE, "created with log_steps = 0");
+  out->idx = E->log.idx; out->step = E->log.step; out->position_index = E->log.pos;
+  out->dataset_index = E->log.dsi; out->portfolio_valuation = E->log.pv;
+  out->real_position = E->log.realpos; out->reward = E->log.reward; out->flags = E->log.flags;
+  out->rows = E->log_rows; out->L = E->cfg.log_steps; out->N = E->p.N;
+  return GTE_OK;
+}
+
+int gte_read_log(gte_env* E, int32_t env_id, int32_t n, int32_t* idx, int32_t* step,
+                 int32_t* position_index, int32_t* dataset_index, double* portfolio_valuation,
+                 double* real_position, double* reward, uint8_t* flags, int32_t* n_out) {
+  if (!E || !n_out) return fail(GTE_ERR_INVALID, "NULL argument");
+  if (E->cfg.log_steps <= 0) return fail(GTE_ERR_STATE, "created with log_steps = 0");
+  const int N = E->p.N, L = E->cfg.log_steps;
+  if (env_id < 0 || env_id >= N) return fail(GTE_ERR_INVALID, "env_id out of range");
+  int64_t have = E->log_rows < L ? E->log_rows : L;
+  if (n > have) n = (int32_t)have;
+  if (n < 0) n = 0;
+  *n_out = n;
+  if (n == 0) return GTE_OK;
+  HIPCHK(hipSetDevice(E->cfg.device));
+  HIPCHK(hipStreamSynchronize(E->stream));
+  // rows first .. first+n-1 (mod L), oldest first: at most two strided 2-D copies per array
+  const int64_t first = (E->log_rows - n) % L;
+  auto pull = [&](void* host, const void* dev, size_t elem) -> int {
+    if (!host) return GTE_OK;
+    const int64_t run1 = (first + n <= L) ? n : (L - first);
+    HIPCHK(hipMemcpy2D(host, elem, (const char*)dev + ((size_t)first * N + env_id) * elem,
+                       (size_t)N * elem, elem, (size_t)run1, hipMemcpyDeviceToHost));
+    if (run1 < n)
+      HIPCHK(hipMemcpy2D((char*)host + run1 * elem, elem, (const char*)dev + (size_t)env_id * elem,
+                         (size_t)N * elem, elem, (size_t)(n - run1), hipMemcpyDeviceToHost));
+    return GTE_OK;
+  };
+  TRY(pull(idx, E->log.idx, 4)); TRY(pull(step, E->log.step, 4));
+  TRY(pull(position_index, E->log.pos, 4)); TRY(pull(dataset_index, E->log.dsi, 4));
+  TRY(pull(portfolio_valuation, E->log.pv, 8)); TRY(pull(real_position, E->log.realpos, 8));
+  TRY(pull(reward, E->log.reward, 8)); TRY(pull(flags, E->log.flags, 1));
   return GTE_OK;
 }
 

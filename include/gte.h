@@ -125,6 +125,10 @@ typedef struct gte_config {
                                envs are re-sorted by (dataset, table region) so that
                                each XCD's L2 serves one region (speed only; results
                                do not depend on it).  0 = default (128), -1 = off   */
+  int32_t log_steps;        /* L > 0: keep the last L steps of every env in a device
+                               trajectory log (what History records each step,
+                               environments.py:253-264); 0 = off                  */
+  int32_t reserved2;
   int32_t final_obs;        /* 1 (needs autoreset = same-step): keep the terminal
                                observation of every env that ends, in
                                gte_outputs.final_obs (Gymnasium `final_observation`,
@@ -219,6 +223,30 @@ int gte_step(gte_env* env, const int32_t* actions, int32_t actions_on_device);
  * (the reference deletes it while iterating and raises RuntimeError). */
 int gte_add_limit_orders(gte_env* env, const int32_t* pos_index, const double* limit,
                          const uint8_t* persistent);
+
+/* Device trajectory log (gte_config.log_steps = L): after every gte_reset / gte_step a small
+ * kernel appends one row per env.  Row r of env e lives at index (r % L) * N + e of each
+ * array; `rows` counts the rows written so far (the newest is rows - 1).  An episode of
+ * env e is the run of rows whose `step` goes 0, 1, 2, ... (step 0 = the reset row). */
+typedef struct gte_log_view {
+  int32_t* idx;             /* i32 [L, N] _idx                                    */
+  int32_t* step;            /* i32 [L, N] _step                                   */
+  int32_t* position_index;  /* i32 [L, N]                                         */
+  int32_t* dataset_index;   /* i32 [L, N]                                         */
+  double*  portfolio_valuation; /* f64 [L, N]                                     */
+  double*  real_position;   /* f64 [L, N]                                         */
+  double*  reward;          /* f64 [L, N]                                         */
+  uint8_t* flags;           /* u8  [L, N] bit0 terminated, bit1 truncated         */
+  int64_t  rows;            /* rows written since gte_create                      */
+  int32_t  L;
+  int32_t  N;
+} gte_log_view;
+int gte_get_log(gte_env* env, gte_log_view* out);
+/* the last `n` (<= L) rows of ONE env, oldest first, into host arrays of length n (any may
+ * be NULL); returns the number of rows copied through *n_out */
+int gte_read_log(gte_env* env, int32_t env_id, int32_t n, int32_t* idx, int32_t* step,
+                 int32_t* position_index, int32_t* dataset_index, double* portfolio_valuation,
+                 double* real_position, double* reward, uint8_t* flags, int32_t* n_out);
 
 /* Where the results of the last gte_step / gte_reset live (device pointers). */
 int gte_get_outputs(gte_env* env, gte_outputs* out);

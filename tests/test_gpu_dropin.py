@@ -229,3 +229,46 @@ def test_batched_episode_metrics_match_single_env_metrics():
     assert m["Market Return"][0] == ref["Market Return"]
     assert m["Portfolio Return"][2] == ref["Portfolio Return"]
     single.close(); batch.close()
+
+
+def test_batched_history_and_custom_metrics_match_single_env(tmp_path):
+    """Device trajectory log -> History: the same columns/values the N=1 drop-in logs, and
+    `add_metric` lambdas over it (examples/example_environnement.py:45-46)."""
+    from gym_trading_env_amd import BatchedTradingEnv, TradingEnv
+    g = replay.load("c2_nowindow")
+    feat, close = g["datasets"][0]
+    df = make_df(feat[:80], close[:80])
+    kw = dict(positions=[-1, 0, 1], trading_fees=1e-4, borrow_interest_rate=3e-6,
+              max_episode_duration=30)
+    single = TradingEnv(df=df, initial_position=0, verbose=0, **kw)
+    batch = BatchedTradingEnv(df, num_envs=5, initial_position=0, output="numpy",
+                              autoreset="next_step", log_steps=64, **kw)
+    changes = lambda history: int(np.sum(np.diff(history["position"]) != 0))
+    length = lambda history: len(history["position"])
+    for env in (single, batch):
+        env.add_metric("Position Changes", changes)
+        env.add_metric("Episode Lenght", length)
+    np.random.seed(3)
+    single.reset()
+    start = single.historical_info["idx", 0]
+    batch.reset(inject_idx=np.full(5, start, np.int32))
+    rng = np.random.default_rng(8)
+    done = trunc = False
+    while not (done or trunc):
+        a = int(rng.integers(0, 3))
+        _, _, done, trunc, _ = single.step(a)
+        batch.step(np.full(5, a, np.int32))
+    hs, hb = single.historical_info, batch.history(3)
+    assert len(hb) == len(hs) == 30
+    for col in ("idx", "step", "position", "portfolio_valuation", "real_position", "reward",
+                "data_close", "data_volume"):
+        np.testing.assert_allclose(np.asarray(hb[col], float), np.asarray(hs[col], float),
+                                   rtol=1e-12, atol=1e-15, err_msg=col)
+    assert list(hb["date"]) == list(hs["date"])
+    m = batch.episode_metrics()
+    ref = single.get_metrics()
+    assert m["Position Changes"][0] == ref["Position Changes"] and m["Episode Lenght"][4] == 30
+    assert m["Market Return"][2] == ref["Market Return"]
+    with pytest.raises(ValueError):
+        BatchedTradingEnv(df, num_envs=2, output="numpy").add_metric("x", length)
+    single.close(); batch.close()
