@@ -23,6 +23,7 @@ hipError_t launch_step(const Params& p, int vec, int nt, bool coop, int stage, i
 hipError_t launch_reset(const Params& p, int vec, int nt, bool coop, int stage, int blocks,
                         int threads, hipStream_t stream);
 size_t lds_bytes(const Params& p, int stage);
+hipError_t launch_step_hot(const Params& p, int blocks, int threads, size_t smem, hipStream_t stream);
 size_t lds_bytes_overlap(const Params& p);
 hipError_t launch_step_overlap(const Params& p, int vec, int nt, hipStream_t stream);
 struct StateSoA {
@@ -541,6 +542,9 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
   p.term_count_next = E->term_base + (E->term_slot ^ 1);
   if (E->overlap)
     HIPCHK(gte::launch_step_overlap(p, E->vec, E->cfg.nontemporal_obs, E->stream));
+  else if (E->vec == 4 && E->cfg.nontemporal_obs == 2 && E->coop && E->stage == 1 &&
+           !(E->cfg.kernel_variant & 64))
+    HIPCHK(gte::launch_step_hot(p, E->blocks, E->threads, gte::lds_bytes(p, E->stage), E->stream));
   else
     HIPCHK(gte::launch_step(p, E->vec, E->cfg.nontemporal_obs, E->coop, E->stage, E->blocks,
                             E->threads, E->stream));

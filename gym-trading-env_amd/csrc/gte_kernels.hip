@@ -144,6 +144,7 @@ __device__ inline void fill_limit_orders(const Params& p, int e, const DatasetDe
   s.lo_n = k;
 }
 
+#ifndef GTE_HOT_ONLY
 // TradingEnv.add_limit_order, environments.py:227-231: `orders[position] = {...}` — an
 // existing key (a position VALUE) keeps its place in the iteration order, a new one
 // goes last.  One thread per env.
@@ -162,6 +163,8 @@ __global__ void gte_add_orders_kernel(const Params p, const int32_t* pos_index,
   p.lo_limit[(int64_t)e * p.P + j] = limit[e];
   p.lo_persist[(int64_t)e * p.P + j] = persistent ? persistent[e] : 0;
 }
+
+#endif  // GTE_HOT_ONLY
 
 __device__ inline void pop_injection(const Params& p, int e, EnvRegs& s, int32_t& qi,
                                      int32_t& qp, int32_t& qd) {
@@ -726,6 +729,7 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
   if (MODE == MODE_STEP && p.final_obs) final_windows<VEC>(p, L, s_first, n_env, lane, fv_magic);
 }
 
+#ifndef GTE_HOT_ONLY
 // ---------------------------------------------------------------------------
 // Overlapped step kernel (default for windowed, non-persist shapes).
 //
@@ -1098,5 +1102,7 @@ hipError_t launch_reset(const Params& p, int vec, int nt, bool coop, int stage, 
                         int threads, hipStream_t stream) {
   return launch_mode<MODE_RESET>(p, vec, nt, coop, stage, blocks, threads, stream);
 }
+
+#endif  // GTE_HOT_ONLY
 
 }  // namespace gte

@@ -116,7 +116,9 @@ typedef struct gte_config {
                                cooperative phase A), 2 = no LDS staging of the
                                dynamic columns, 4 = overlapped step kernel (waves
                                1-3 gather predicted windows during phase A)
-                               instead of the classic one (csrc/gte_kernels.hip) */
+                               instead of the classic one (csrc/gte_kernels.hip),
+                               64 = launch the shared-TU instantiation of the hot
+                               kernel instead of the isolated one (gte_hot.hip)   */
   int32_t debug_flags;      /* timing ablations only (results become wrong):
                                1 = skip the observation gather, 2 = skip the
                                dynamic-column patch, 8 = skip the window loads

@@ -296,7 +296,8 @@ def test_hip_vs_oracle_shape_sweep(oracle_mod, shape, autoreset):
                          max_episode_duration=max_dur, autoreset=autoreset)
 
 
-@pytest.mark.parametrize("variant,store", [(4, 1), (4, 2), (4, 0), (0, 1), (0, 0), (1, 2), (2, 2)])
+@pytest.mark.parametrize("variant,store", [(4, 1), (4, 2), (4, 0), (0, 1), (0, 0), (1, 2), (2, 2),
+                                           (64, 2)])
 def test_hip_vs_oracle_kernel_variants(oracle_mod, variant, store):
     """Every selectable kernel structure (classic / overlapped / per-wave phase A / no LDS
     staging) and store policy (plain / nt / sc1) gives the same results."""
