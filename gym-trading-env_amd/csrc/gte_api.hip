@@ -735,6 +735,15 @@ int gte_get_launch_info(gte_env* E, int32_t* envs_per_wave, int32_t* threads_per
   return GTE_OK;
 }
 
+#ifdef GTE_STAMPS
+// diagnostic build only: device buffer of u64 [n_blocks, 8] for the kernel's time stamps
+int gte_debug_set_stamps(gte_env* E, void* device_buf) {
+  if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
+  E->p.inj_ds = (const int32_t*)device_buf;
+  return GTE_OK;
+}
+#endif
+
 void gte_destroy(gte_env* E) {
   if (!E) return;
   (void)hipSetDevice(E->cfg.device);

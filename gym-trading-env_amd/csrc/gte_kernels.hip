@@ -37,6 +37,22 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 
 enum { MODE_STEP = 0, MODE_RESET = 1 };
 
+// Diagnostic build only (-DGTE_STAMPS, libgte_stamps.so, never shipped): lane 0 of a
+// workgroup's wave 0 records s_memrealtime (100 MHz) at a few points of the step kernel into
+// the buffer whose address the host passes in p.inj_ds (unused by a step).
+#ifdef GTE_STAMPS
+#define GTE_STAMP(k)                                                                          \
+  do {                                                                                        \
+    if (MODE == MODE_STEP && p.inj_ds) {                                                      \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); /* mark data ARRIVAL */      \
+      if (threadIdx.x == 0)                                                                   \
+        ((unsigned long long*)p.inj_ds)[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    }                                                                                         \
+  } while (0)
+#else
+#define GTE_STAMP(k) do {} while (0)
+#endif
+
 struct EnvRegs {
   int32_t idx, step, pos, dsi, start, episode, needs_reset, eps_on_ds, n_picks, q_head, lo_n;
   Portfolio q;
@@ -277,6 +293,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
     load_state(p, e, s);
     if (old) { old->idx = s.idx; old->dsi = s.dsi; old->start = s.start; old->needs_reset = s.needs_reset; }
     int32_t action = p.actions[e];
+    GTE_STAMP(2);  // record + action arrived
     // positions[position_index] raises IndexError in the reference (:234); a device-side
     // action cannot raise, so an out-of-range index is treated as None (hold), never read
     if (action >= p.P) action = -1;
@@ -311,6 +328,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
       s.step += 1;  // :236
       if (p.lo_pos) fill_limit_orders(p, e, d, s);  // :238
       const double price = d.close[s.idx];  // :239
+      GTE_STAMP(3);  // descriptor, positions, trade, price at the new row arrived
       s.q.ia = pymax0(-s.q.asset) * p.rate;   // update_interest, portfolio.py:44-46
       s.q.ifi = pymax0(-s.q.fiat) * p.rate;
       const double pv = valorisation(s.q, price);  // :241
@@ -349,8 +367,10 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
         }
       }
     }
+    GTE_STAMP(4);  // state machine done, outputs issued
     store_state(p, e, s);
     make_job(p, e, s, fresh, job);
+    GTE_STAMP(5);  // record, ring and job stores done
   }
 
   // terminal-mask compaction: one atomic per wave, ids in lane order within a wave
@@ -684,21 +704,33 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
   const int wg_first = blockIdx.x * EPB;
   if (wg_first >= p.N) return;  // whole workgroup exits together (before any barrier)
   const int n_wg = min(EPB, p.N - wg_first);
+  GTE_STAMP(0);
   const WgLds L = carve_lds(gte_smem, EPB, p.final_obs != nullptr);
   const int s_first = wib * p.epw;
   const int n_env = min(p.epw, n_wg - s_first);
-  // which env each slot of this wave processes: the identity, or the L2-affinity
-  // permutation (envs reading the same table region share an XCD, see gte_api.hip)
-  if (lane < p.epw) {
-    const int slot = wg_first + s_first + lane;
-    L.job[s_first + lane].env = (lane < n_env) ? (p.perm ? p.perm[slot] : slot) : -1;
+  // Which env each slot processes (identity, or the L2-affinity permutation), and the raw
+  // rings into LDS.  With cooperative phase A wave 0 goes straight to the state machine
+  // (the in-kernel timeline showed it spending 2.8 us staging its own rings first): wave 1
+  // covers wave 0's slots as well as its own.
+  auto prepare = [&](int first, int count) {
+    if (lane < p.epw) {
+      const int slot = wg_first + first + lane;
+      L.job[first + lane].env = (lane < count) ? (p.perm ? p.perm[slot] : slot) : -1;
+    }
+    if (STAGE == STAGE_RAW && count > 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      stage_raw_rings(p, L, first, count, lane, wnd_magic);
+    }
+  };
+  if (!COOP) {
+    prepare(s_first, n_env);
+  } else if (wib >= 1) {
+    prepare(s_first, n_env);
+    if (wib == 1) prepare(0, min(p.epw, n_wg));
   }
-  if (STAGE == STAGE_RAW && n_env > 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    stage_raw_rings(p, L, s_first, n_env, lane, wnd_magic);
-  }
+  GTE_STAMP(1);  // env ids (perm) + rings arrived
 
   // ---- phase A
   if (!COOP || wib == 0) {  // wave-uniform
@@ -712,7 +744,11 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
     if (owns) publish_job(L, s, job);  // slots past the last env get flags = 0
     if (owns && p.final_obs) L.fin[s] = fin;
   }
-  __syncthreads();
+  // Only LDS has to be visible across the barrier (jobs, env ids, staged rings): nothing
+  // after it reads global memory written before it in this launch.  __syncthreads() would
+  // also drain wave 0's global stores (record, outputs, ring: 2.5 us in the timeline).
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  GTE_STAMP(6);
 
   // ---- phase B: each wave gathers the windows of its own EPW envs
   if (n_env <= 0 || (p.debug & 1)) return;
@@ -726,6 +762,7 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   phase_b<VEC, NT, STAGE, 4>(p, L, s_first, n_env, lane, vpe_magic, fv_magic);
+  GTE_STAMP(7);
   if (MODE == MODE_STEP && p.final_obs) final_windows<VEC>(p, L, s_first, n_env, lane, fv_magic);
 }
 
