@@ -294,7 +294,9 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   const int64_t vpe = (int64_t)p.W * p.Fobs / E->vec;  // vectors per env
   int epw = cfg->envs_per_wave;
   if (epw == 0) {
-    epw = 64;
+    // windows of at least one wave instruction: 16 envs per wave (64 per workgroup, cooperative
+    // phase A) measured best at every size tried; tiny windows may pack up to 64 per wave
+    epw = (vpe >= 64) ? 16 : 64;
     // enough wavefronts to fill 256 CUs x 16 waves ...
     while (epw > 1 && ((int64_t)p.N + epw - 1) / epw < 4096) epw >>= 1;
     // ... but at least one full wave instruction (64 vectors) of copy work per wavefront

@@ -75,3 +75,11 @@ def test_config3_invariants_long_run():
     assert ended_total >= N
     assert (env.state("episode") >= 2).all()
     env.close()
+
+
+def test_config4_total_size_on_one_gpu_vs_oracle(oracle_mod):
+    """262 144 envs (config 4's node total) on one GPU: 671 MB of observations per step;
+    checks 64-bit offsets end to end."""
+    ds = [_synthetic(1234, 100_000, 30, sigma=1e-3)]
+    _compare_with_oracle(oracle_mod, ds, n_envs=262_144, steps=12, seed=14, check_every=6,
+                         max_episode_duration=7, **C3)
