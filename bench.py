@@ -136,10 +136,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the env has no CPU fallback")
+    # rehearsal knobs (a 1-GPU box can run 2 ranks on its one device over gloo; RCCL refuses
+    # two ranks per device): GTE_BENCH_BACKEND=gloo GTE_BENCH_SHARE_DEVICE=1
+    backend = os.environ.get("GTE_BENCH_BACKEND", "nccl")
+    if os.environ.get("GTE_BENCH_SHARE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from gym_trading_env_amd.batched import BatchedTradingEnv
@@ -208,7 +216,7 @@ def main():
     achieved = b_alg * N / (kernel_us * 1e-6) / 1e9
     traffic = None
     tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tp):
+    if os.path.exists(tp) and N == wl["envs"]:  # the counters were collected at the default size
         try:
             traffic = json.load(open(tp)).get(f"{args.workload}_bytes_per_launch")
         except Exception:
