@@ -394,5 +394,38 @@ def main():
                  f"lives across episodes, so that trace needs dyn_persist")
 
 
+def portfolio_vectors():
+    """Random known answers straight from the reference's Portfolio class
+    (utils/portfolio.py:1-66, which imports nothing): every branch of trade_to_position
+    (interest repayment on both sides, buys, sells, leverage, shorts)."""
+    from gym_trading_env.utils.portfolio import Portfolio, TargetPortfolio
+    rng = np.random.default_rng(777)
+    n = 3000
+    inp = np.zeros((n, 9)); out = np.zeros((n, 6))
+    for k in range(n):
+        price = float(np.exp(rng.normal(4, 1)))
+        start_pos = float(rng.choice([-2, -1, -0.5, 0, 0.3, 1, 1.5, 2, 3]))
+        pf = TargetPortfolio(position=start_pos, value=float(rng.uniform(100, 5000)), price=price)
+        rate = float(rng.choice([0, 1e-5, 1e-3]))
+        pf.update_interest(rate)                      # some accrued interest to repay
+        if rng.random() < 0.3:
+            pf.interest_asset *= float(rng.uniform(1, 50)); pf.interest_fiat *= float(rng.uniform(1, 50))
+        position = float(rng.choice([-2, -1, -0.5, 0, 0.5, 1, 1.5, 2, 3]))
+        fees = float(rng.choice([0, 1e-4, 1e-3, 1e-2]))
+        trade_px = price * float(np.exp(rng.normal(0, 0.05)))
+        next_px = trade_px * float(np.exp(rng.normal(0, 0.05)))
+        inp[k] = (pf.asset, pf.fiat, pf.interest_asset, pf.interest_fiat, position, trade_px, fees, rate, next_px)
+        pf.trade_to_position(position, trade_px, fees)
+        pf.update_interest(rate)
+        out[k] = (pf.asset, pf.fiat, pf.interest_asset, pf.interest_fiat, pf.valorisation(next_px),
+                  pf.real_position(next_px))
+    np.savez_compressed(os.path.join(HERE, "portfolio_random.npz"), inputs=inp, outputs=out,
+                        note=np.array("columns: asset, fiat, interest_asset, interest_fiat, position, "
+                                      "trade_price, fees, rate, next_price -> asset, fiat, interest_asset, "
+                                      "interest_fiat, valorisation(next), real_position(next)"))
+    print("portfolio_random:", n, "vectors")
+
+
 if __name__ == "__main__":
     main()
+    portfolio_vectors()

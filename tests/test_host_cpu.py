@@ -143,3 +143,5 @@ def test_golden_fixtures_are_data_only():
     for n in names:
         z = np.load(os.path.join(replay.GOLDEN_DIR, n + ".npz"), allow_pickle=False)
         assert "obs" in z.files and "cfg_json" in z.files
+    z = np.load(os.path.join(replay.GOLDEN_DIR, "portfolio_random.npz"), allow_pickle=False)
+    assert z["inputs"].shape == (3000, 9) and z["outputs"].shape == (3000, 6)

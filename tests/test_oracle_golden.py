@@ -75,3 +75,16 @@ def test_philox_known_answers(oracle_mod):
     assert list(oracle_mod.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
                                   [0xa4093822, 0x299f31d0])) == [
         0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_portfolio_random_known_answers(oracle_mod):
+    """3 000 random states / trades computed by the reference's Portfolio class itself
+    (tests/golden/make_golden.py:portfolio_vectors): the oracle must agree bit for bit."""
+    import os
+    z = np.load(os.path.join(replay.GOLDEN_DIR, "portfolio_random.npz"), allow_pickle=False)
+    bad = 0
+    for row, exp in zip(z["inputs"], z["outputs"]):
+        s, v, r = oracle_mod.portfolio_trade(row[:4], row[4], row[5], row[6], row[7], row[8])
+        got = np.array([s[0], s[1], s[2], s[3], v, r])
+        bad += int((got != exp).sum())
+    assert bad == 0
