@@ -125,8 +125,19 @@ def main():
     ap.add_argument("--affinity", type=int, default=0,
                     help="L2-affinity re-sort period in steps (0 = default 128, -1 = off)")
     ap.add_argument("--gather-obs", action="store_true", help="also all-gather observations (N>1)")
+    ap.add_argument("--gather-every", type=int, default=16,
+                    help="N>1: all-gather the returns in blocks of this many steps (every step's "
+                         "reward/flags still cross xGMI inside the timed region; 1 = per step)")
+    ap.add_argument("--gather-depth", type=int, default=2,
+                    help="N>1: blocks in rotation (>=2: a block's all-gather overlaps the steps "
+                         "that fill the next one on RCCL's stream; 1 = synchronous per-step gather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a
+    # version banner at communicator creation), so everything but that line goes to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -143,14 +154,22 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # GTE_BENCH_FORCE_DIST=1: rehearse the N>1 code path with a 1-rank group on one GPU
+    force_dist = world == 1 and bool(os.environ.get("GTE_BENCH_FORCE_DIST"))
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+    use_dist = world > 1 or force_dist
+    if use_dist:
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)  # RCCL over xGMI
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from gym_trading_env_amd.batched import BatchedTradingEnv
+    depth = max(1, args.gather_depth)
+    block = max(1, args.gather_every) if depth > 1 else 1
 
     wl = WORKLOADS[args.workload]
     N = args.envs or wl["envs"]
@@ -165,6 +184,7 @@ def main():
                             env_id_base=rank * N,
                             device=local_rank, output="torch", envs_per_wave=args.epw,
                             **({} if args.nt < 0 else {'nontemporal_obs': args.nt}), kernel_variant=args.variant, affinity_period=args.affinity,
+                            return_slots=(max(1, args.gather_depth) * block) if use_dist else 1,
                             **env_kwargs(wl))
     gen = torch.Generator(device=dev)
     gen.manual_seed(99 + rank)
@@ -175,20 +195,32 @@ def main():
     # per-step return of a sharded run: one RCCL all-gather of the packed
     # (reward f32 | terminated u8 | truncated u8) records, 6 bytes per env, which the
     # kernel writes directly in that layout (env.packed_returns)
-    returns = None
-    if world > 1:
-        from gym_trading_env_amd.distributed import ReturnGather
-        returns = ReturnGather(N, dev, obs_shape=env.obs_shape if args.gather_obs else None)
+    returns = pipe = None
+    if use_dist:
+        from gym_trading_env_amd.distributed import ReturnGather, ReturnPipeline
+        returns = ReturnGather(N, dev, obs_shape=env.obs_shape if args.gather_obs else None,
+                               depth=depth, block=block)
+        if depth > 1:
+            pipe = ReturnPipeline(env, returns, block, depth)
+
+    def drain():
+        if pipe is not None:
+            pipe.flush()  # incl. a block the step count left unfinished
 
     def one_step(i):
+        if pipe is not None:
+            pipe.before_step()  # rows about to be rewritten must have been gathered
         obs, reward, term, trunc, _ = env.step(actions[i % n_rows])
-        if returns is not None:
+        if pipe is not None:
+            pipe.after_step()   # starts the block's all-gather on block boundaries
+        elif returns is not None:
             returns.gather(env.packed_returns)
-            if args.gather_obs:
-                returns.gather_obs(obs)
+        if returns is not None and args.gather_obs:
+            returns.gather_obs(obs)
 
     for i in range(args.warmup):
         one_step(i)
+    drain()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -197,6 +229,7 @@ def main():
     env.timer_start()  # HIP events on the stream the kernel is launched on
     for i in range(args.steps):
         one_step(args.warmup + i)
+    drain()  # every all-gather belongs to the timed region
     ev_ms = env.timer_stop()
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -233,7 +266,9 @@ def main():
                        "envs_per_gpu": N, "global_envs": world * N,
                        "parallelism": f"env-shard x{world}" + (
                            "" if world == 1 else " + RCCL all-gather(reward,flags"
-                           + (",obs)" if args.gather_obs else ")")),
+                           + (",obs)" if args.gather_obs else ")")
+                           + (f" in {block}-step blocks overlapping the following steps"
+                              if depth > 1 else ", synchronous per step")),
                        "launch": info, "store_policy": int(env.cfg.nontemporal_obs),
                        "episodes_finished": episodes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -254,9 +289,9 @@ def main():
                         "env_steps_per_s": ref["shapes"].get(args.workload)}
                 except Exception:
                     pass
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     env.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

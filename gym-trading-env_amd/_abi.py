@@ -145,6 +145,7 @@ SYMBOLS = {
     "gte_get_outputs": (C.c_int, [C.c_void_p, _P(GteOutputs)]),
     "gte_get_state": (C.c_int, [C.c_void_p, _P(GteStateView)]),
     "gte_bind_outputs": (C.c_int, [C.c_void_p, _P(GteOutputs)]),
+    "gte_bind_returns": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gte_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gte_use_own_stream": (C.c_int, [C.c_void_p]),
     "gte_synchronize": (C.c_int, [C.c_void_p]),

@@ -141,7 +141,7 @@ class BatchedTradingEnv(_VectorEnvBase):
                  episodes_between_dataset_switch=1, dyn_persist=False, seed=0,
                  env_id_base=0, device=0, output="torch", envs_per_wave=0,
                  nontemporal_obs=2, kernel_variant=0, library_path=None, debug_flags=0,
-                 affinity_period=0, final_obs=False, log_steps=0):
+                 affinity_period=0, final_obs=False, log_steps=0, return_slots=1):
         assert render_mode is None or render_mode in self.metadata["render_modes"]
         if output not in ("torch", "numpy"):
             raise ValueError("output must be 'torch' or 'numpy'")
@@ -150,6 +150,13 @@ class BatchedTradingEnv(_VectorEnvBase):
         self.verbose, self.name, self.render_mode = verbose, name, render_mode
         self.num_envs = int(num_envs)
         self.output = output
+        # return_slots=K > 1 (torch output): step t writes reward/terminated/truncated into
+        # row t % K of one [K, 6N] buffer, so a collective still reading older returns is not
+        # overwritten by the next K-1 steps, and runs of consecutive steps are contiguous
+        # blocks (distributed.ReturnPipeline gathers them a block at a time)
+        self.return_slots = int(return_slots)
+        if self.return_slots < 1 or (self.return_slots > 1 and output != "torch"):
+            raise ValueError("return_slots must be >= 1 (and > 1 only with output='torch')")
         self.metadata = dict(self.metadata, autoreset_mode=autoreset or "disabled")
         self.closed = False
         self._lib = _abi.load_library(library_path)  # raises if the HIP build is missing
@@ -245,7 +252,12 @@ class BatchedTradingEnv(_VectorEnvBase):
         with torch.cuda.device(dev):
             # reward | terminated | truncated live in ONE buffer (distributed.packed_layout)
             # so that a sharded run all-gathers it without a packing kernel
-            self.packed_returns = torch.zeros(6 * N, dtype=torch.uint8, device=dev)
+            self._packed_all = torch.zeros((self.return_slots, 6 * N), dtype=torch.uint8,
+                                           device=dev)
+            self._packed = list(self._packed_all.unbind(0))
+            # outputs start bound to row 0 (reset writes there); the first step rotates to it
+            self._ret_slot = self.return_slots - 1
+            self.packed_returns = self._packed[0]
             self._t = {
                 "obs": torch.zeros((N,) + self.obs_shape, dtype=torch.float32, device=dev),
                 "reward": self.packed_returns[:4 * N].view(torch.float32),
@@ -380,6 +392,32 @@ class BatchedTradingEnv(_VectorEnvBase):
                 out[metric["name"]] = [metric["function"](h) for h in hists]
         return out
 
+    def _rotate_returns(self):
+        """Point the next step at the next packed return buffer (gte_bind_returns)."""
+        N = self.num_envs
+        self._ret_slot = (self._ret_slot + 1) % self.return_slots
+        buf = self._packed[self._ret_slot]
+        base = buf.data_ptr()
+        _abi.check(self._lib, self._lib.gte_bind_returns(
+            self._h, C.c_void_p(base), C.c_void_p(base + 4 * N), C.c_void_p(base + 5 * N)))
+        self.packed_returns = buf
+        self._out.reward, self._out.terminated, self._out.truncated = base, base + 4 * N, base + 5 * N
+        t = self._t
+        t["reward"] = buf[:4 * N].view(self._torch.float32)
+        t["terminated"] = buf[4 * N:5 * N].view(self._torch.bool)
+        t["truncated"] = buf[5 * N:].view(self._torch.bool)
+
+    @property
+    def return_slot(self) -> int:
+        """Row of the [return_slots, 6N] buffer the NEXT step writes its returns into."""
+        return (self._ret_slot + 1) % self.return_slots
+
+    def return_block(self, first: int, count: int):
+        """uint8 [count, 6N]: the packed returns in rows first..first+count-1 (contiguous)."""
+        if not (0 <= first and first + count <= self.return_slots):
+            raise IndexError("return block out of range")
+        return self._packed_all[first:first + count]
+
     def _results(self):
         if self.output == "torch":
             t = self._t
@@ -451,6 +489,8 @@ class BatchedTradingEnv(_VectorEnvBase):
             if actions.shape != (self.num_envs,):
                 raise ValueError(f"expected {self.num_envs} actions")
             self._keep = actions  # keep alive until the launch has consumed it
+            if self.return_slots > 1:
+                self._rotate_returns()
             _abi.check(self._lib, self._lib.gte_step(self._h, C.c_void_p(actions.data_ptr()), 1))
         else:
             if torch is not None and isinstance(actions, torch.Tensor):

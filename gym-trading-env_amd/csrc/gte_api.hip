@@ -660,6 +660,16 @@ int gte_bind_outputs(gte_env* E, const gte_outputs* b) {
   return GTE_OK;
 }
 
+int gte_bind_returns(gte_env* E, float* reward, uint8_t* terminated, uint8_t* truncated) {
+  if (!E || !reward || !terminated || !truncated) return fail(GTE_ERR_INVALID, "NULL argument");
+  // Params travel by value with every launch: later launches see the new pointers,
+  // launches already enqueued keep the old ones.
+  E->p.reward = reward;
+  E->p.terminated = terminated;
+  E->p.truncated = truncated;
+  return GTE_OK;
+}
+
 int gte_get_state(gte_env* E, gte_state_view* out) {
   if (!E || !out) return fail(GTE_ERR_INVALID, "NULL argument");
   // the state lives in 128-byte records; snapshot it into struct-of-arrays mirrors

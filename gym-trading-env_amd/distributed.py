@@ -49,29 +49,57 @@ class ReturnGather:
 
     `gather(packed)` -> (reward f32 [world, n], terminated bool [world, n],
     truncated bool [world, n]) as zero-copy views of the gathered buffer; row r is
-    rank r's shard, i.e. global env ids r*n .. r*n+n-1."""
+    rank r's shard, i.e. global env ids r*n .. r*n+n-1.  With `block=K > 1` one call moves
+    the returns of K consecutive steps (uint8 [K, 6n] in, views [world, K, n] out)."""
 
-    def __init__(self, n_local: int, device, group=None, obs_shape=None):
+    def __init__(self, n_local: int, device, group=None, obs_shape=None, depth=1, block=1):
         self.group = group
         self.world = dist.get_world_size(group)
         self.n = int(n_local)
+        self.block = max(1, int(block))
         self.lay = packed_layout(self.n)
-        self.buf = torch.empty(self.world * self.lay["bytes"], dtype=torch.uint8, device=device)
+        self.nbytes = self.block * self.lay["bytes"]
+        # `depth` gathered buffers: gather_async() may have that many collectives in flight
+        self.bufs = [torch.empty(self.world * self.nbytes, dtype=torch.uint8, device=device)
+                     for _ in range(max(1, int(depth)))]
+        self.buf = self.bufs[0]
+        self._turn = 0
         self.obs_buf = None
         if obs_shape is not None:
             self.obs_buf = torch.empty((self.world * self.n,) + tuple(obs_shape),
                                        dtype=torch.float32, device=device)
 
+    def _check(self, packed):
+        if packed.numel() != self.nbytes or packed.dtype != torch.uint8 or not packed.is_contiguous():
+            raise ValueError(f"packed must be contiguous uint8 [{self.block} x 6*n_local]")
+
     def gather(self, packed: torch.Tensor):
-        if packed.numel() != self.lay["bytes"] or packed.dtype != torch.uint8:
-            raise ValueError("packed must be uint8 [6*n_local]")
-        dist.all_gather_into_tensor(self.buf, packed, group=self.group)
-        rows = self.buf.view(self.world, self.lay["bytes"])
+        self._check(packed)
+        dist.all_gather_into_tensor(self.buf, packed.view(-1), group=self.group)
+        return self._views(self.buf)
+
+    def _views(self, buf):
+        rows = buf.view(self.world, self.block, self.lay["bytes"])
+        if self.block == 1:
+            rows = rows[:, 0]
         r0, r1 = self.lay["reward"]
         t0, t1 = self.lay["terminated"]
         u0, u1 = self.lay["truncated"]
-        return (rows[:, r0:r1].view(torch.float32), rows[:, t0:t1].view(torch.bool),
-                rows[:, u0:u1].view(torch.bool))
+        return (rows[..., r0:r1].view(torch.float32), rows[..., t0:t1].view(torch.bool),
+                rows[..., u0:u1].view(torch.bool))
+
+    def gather_async(self, packed: torch.Tensor) -> "PendingReturns":
+        """Start the all-gather and return at once; `.wait()` on the result gives the views.
+
+        The collective runs on the backend's own stream (RCCL), ordered after everything
+        already enqueued on the current stream, so the NEXT step's kernel overlaps it.
+        `packed` must not be rewritten before `.wait()`: use BatchedTradingEnv(return_slots=K)
+        and keep at most K-1 gathers pending while stepping (K = `depth` here)."""
+        self._check(packed)
+        buf = self.bufs[self._turn]
+        self._turn = (self._turn + 1) % len(self.bufs)
+        work = dist.all_gather_into_tensor(buf, packed.view(-1), group=self.group, async_op=True)
+        return PendingReturns(self, buf, work)
 
     def gather_obs(self, obs: torch.Tensor) -> torch.Tensor:
         """obs f32 [n, ...] -> [world*n, ...] (config 4: xGMI-bound, 2 560 B per env)."""
@@ -81,6 +109,83 @@ class ReturnGather:
         return self.obs_buf
 
 
+class PendingReturns:
+    """An all-gather in flight (ReturnGather.gather_async)."""
+
+    def __init__(self, owner: ReturnGather, buf, work):
+        self._owner, self._buf, self._work = owner, buf, work
+
+    def wait(self):
+        """Order the current stream (GPU backends) / the host (gloo) after the collective
+        and return (reward [world, n], terminated [world, n], truncated [world, n])."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._owner._views(self._buf)
+
+
+class ReturnPipeline:
+    """Block-wise, overlapped all-gather of a BatchedTradingEnv's returns.
+
+    The env is built with `return_slots = depth * block`: step t writes row t % slots of one
+    [slots, 6n] buffer.  Every `block` steps the finished block (contiguous rows) is
+    all-gathered asynchronously on the collective's stream while the following steps fill the
+    next block; a block is waited for only when its rows are about to be rewritten, `depth`
+    blocks later.  Per step this costs no cross-stream dependency and no host work except on
+    block boundaries (measured on one MI355X with a 1-rank RCCL group, config 3: synchronous
+    per-step gather 51 us/step, per-step asynchronous 58-68 us/step — host and cross-stream
+    bound —, block=16 43.9 us/step, no gather 42.4 us/step; profiles/r01_gather_rehearsal.md).
+    block=1, depth>=2 is the per-step form."""
+
+    def __init__(self, env, returns: ReturnGather, block: int, depth: int):
+        if depth < 2 or block < 1:
+            raise ValueError("ReturnPipeline needs depth >= 2 and block >= 1")
+        if env.return_slots != block * depth or returns.block != block or len(returns.bufs) < depth:
+            raise ValueError("env.return_slots must be block*depth and the ReturnGather must "
+                             "be built with the same block and depth")
+        self.env, self.returns, self.block, self.depth = env, returns, block, depth
+        self._pending = [None] * depth
+
+    def before_step(self):
+        s = self.env.return_slot
+        if s % self.block == 0:  # the step is about to rewrite the first row of block b
+            b = s // self.block
+            if self._pending[b] is not None:
+                self._pending[b].wait()
+                self._pending[b] = None
+
+    def after_step(self):
+        """-> PendingReturns when the step completed a block, else None."""
+        s = self.env._ret_slot
+        if s % self.block != self.block - 1:
+            return None
+        b = s // self.block
+        h = self.returns.gather_async(self.env.return_block(b * self.block, self.block))
+        self._pending[b] = h
+        return h
+
+    def drain(self):
+        for b, h in enumerate(self._pending):
+            if h is not None:
+                h.wait()
+                self._pending[b] = None
+
+    def flush(self):
+        """Gather the block in progress too (its unwritten rows travel as they are), then
+        wait for everything: after it, every step taken so far has had its returns gathered.
+        -> PendingReturns of the partial block, or None when the last step closed a block."""
+        h = None
+        s = self.env._ret_slot
+        if s % self.block != self.block - 1:
+            b = s // self.block
+            if self._pending[b] is not None:
+                self._pending[b].wait()
+            h = self.returns.gather_async(self.env.return_block(b * self.block, self.block))
+            self._pending[b] = h
+        self.drain()
+        return h
+
+
 class ShardedTradingEnv:
     """This rank's shard of a `global_envs`-environment BatchedTradingEnv.
 
@@ -88,7 +193,8 @@ class ShardedTradingEnv:
     terminated / truncated ([world, n_local] views); `gather_obs=True` also returns the
     global observations instead of the local ones."""
 
-    def __init__(self, df, global_envs: int, *, group=None, device=None, gather_obs=False, **kw):
+    def __init__(self, df, global_envs: int, *, group=None, device=None, gather_obs=False,
+                 pipeline=1, block=1, **kw):
         from .batched import BatchedTradingEnv
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
@@ -96,22 +202,56 @@ class ShardedTradingEnv:
             raise ValueError("global_envs must be a multiple of the world size")
         self.first, self.n_local = shard_range(global_envs, self.world, self.rank)
         dev_index = torch.cuda.current_device() if device is None else device
+        self.pipeline, self.block = max(1, int(pipeline)), max(1, int(block))
+        if self.block > 1 and self.pipeline < 2:
+            raise ValueError("block > 1 needs pipeline >= 2")
         self.env = BatchedTradingEnv(df, num_envs=self.n_local, env_id_base=self.first,
-                                     device=dev_index, output="torch", **kw)
+                                     device=dev_index, output="torch",
+                                     return_slots=self.pipeline * self.block, **kw)
         self.gather_obs = gather_obs
-        self.returns = ReturnGather(self.n_local, self.env.packed_returns.device, group,
-                                    obs_shape=self.env.obs_shape if gather_obs else None)
+        dev = self.env.packed_returns.device
+        obs_shape = self.env.obs_shape if gather_obs else None
+        # step(): synchronous per-step gather; step_async(): the pipeline (own buffers)
+        self.returns = ReturnGather(self.n_local, dev, group, obs_shape=obs_shape)
+        self._pipe = None
+        if self.pipeline >= 2:
+            self._pipe = ReturnPipeline(self.env, ReturnGather(self.n_local, dev, group,
+                                                               depth=self.pipeline, block=self.block),
+                                        self.block, self.pipeline)
 
     def reset(self, **kw):
         obs, info = self.env.reset(**kw)
         return (self.returns.gather_obs(obs) if self.gather_obs else obs), info
 
     def step(self, local_actions):
+        if self._pipe is not None:
+            self._pipe.before_step()  # never rewrite rows a pending block gather still reads
         obs, _, _, _, info = self.env.step(local_actions)
         reward, term, trunc = self.returns.gather(self.env.packed_returns)
         if self.gather_obs:
             obs = self.returns.gather_obs(obs)
         return obs, reward, term, trunc, info
 
+    def step_async(self, local_actions):
+        """step() whose global returns arrive later: -> (local obs, pending | None, info).
+
+        Needs `pipeline=P >= 2`.  Every `block`-th call returns a PendingReturns for the block
+        of steps just completed (None otherwise); its all-gather runs on the collective's
+        stream while the following steps execute — each GPU acts on its LOCAL observations,
+        the global returns are what the learner consumes a rollout block at a time.
+        `.wait()` gives (reward, terminated, truncated) as [world, n_local] (block=1) or
+        [world, block, n_local]; those views are reused P blocks later."""
+        if self._pipe is None:
+            raise ValueError("step_async needs ShardedTradingEnv(pipeline >= 2)")
+        self._pipe.before_step()
+        obs, _, _, _, info = self.env.step(local_actions)
+        return obs, self._pipe.after_step(), info
+
+    def drain(self):
+        """Wait for every all-gather started by step_async."""
+        if self._pipe is not None:
+            self._pipe.drain()
+
     def close(self):
+        self.drain()
         self.env.close()

@@ -261,6 +261,14 @@ int gte_get_state(gte_env* env, gte_state_view* out);
 /* Use caller-owned device buffers for the outputs (e.g. torch tensors that are
  * then all-gathered over RCCL).  NULL members keep the library's buffer. */
 int gte_bind_outputs(gte_env* env, const gte_outputs* bufs);
+/* Redirect ONLY the per-step returns (reward f32[N], terminated u8[N], truncated u8[N]) of
+ * the steps enqueued AFTER this call; nothing is synchronised and nothing already
+ * enqueued changes.  A sharded run rotates between two (or more) caller-owned return
+ * buffers with it, so that the RCCL all-gather of step t's returns (environments.py:272,
+ * the `reward, done, truncated` a caller gets back) overlaps step t+1 on another stream.
+ * All three pointers are required; the caller keeps the buffers alive while steps that
+ * write them or collectives that read them are in flight. */
+int gte_bind_returns(gte_env* env, float* reward, uint8_t* terminated, uint8_t* truncated);
 
 /* Run on exactly this hipStream_t; NULL is HIP's null (default) stream, which is
  * what PyTorch's default stream is.  A new env runs on a private non-blocking

@@ -35,24 +35,126 @@ def _worker(rank, world, port, out_dir):
     first, n = shard_range(G, world, rank)
     env = oracle.OracleEnv(make_config(n_envs=n, n_static=3, env_id_base=first, **KW), [_data()])
     env.reset()
-    rg = ReturnGather(n, "cpu", obs_shape=(4, 5))
+    rg = ReturnGather(n, "cpu", obs_shape=(4, 5), depth=2)
     actions = np.random.default_rng(5).integers(-1, 3, (STEPS, G)).astype(np.int32)
     rec = []
+    slots = [torch.empty(6 * n, dtype=torch.uint8) for _ in range(2)]  # rotating sources
+    pending = None  # (handle, obs) of the previous step: the pipelined form, depth 2
     for k in range(STEPS):
         env.step(actions[k, first:first + n])
         packed = pack_returns(torch.from_numpy(env.reward.copy()),
                               torch.from_numpy(env.terminated.copy()).bool(),
-                              torch.from_numpy(env.truncated.copy()).bool())
-        reward, term, trunc = rg.gather(packed)
-        obs = rg.gather_obs(torch.from_numpy(env.obs.copy()))
-        rec.append((reward.reshape(-1).numpy().copy(), term.reshape(-1).numpy().copy(),
-                    trunc.reshape(-1).numpy().copy(), obs.numpy().copy()))
+                              torch.from_numpy(env.truncated.copy()).bool(), out=slots[k % 2])
+        obs = rg.gather_obs(torch.from_numpy(env.obs.copy())).numpy().copy()
+        if k < STEPS // 2:  # synchronous gather
+            reward, term, trunc = rg.gather(packed)
+            rec.append((reward.reshape(-1).numpy().copy(), term.reshape(-1).numpy().copy(),
+                        trunc.reshape(-1).numpy().copy(), obs))
+            continue
+        handle = rg.gather_async(packed)  # step k's gather is consumed during step k+1
+        if pending is not None:
+            reward, term, trunc = pending[0].wait()
+            rec.append((reward.reshape(-1).numpy().copy(), term.reshape(-1).numpy().copy(),
+                        trunc.reshape(-1).numpy().copy(), pending[1]))
+        pending = (handle, obs)
+    reward, term, trunc = pending[0].wait()
+    rec.append((reward.reshape(-1).numpy().copy(), term.reshape(-1).numpy().copy(),
+                trunc.reshape(-1).numpy().copy(), pending[1]))
     if rank == 0:
         np.savez(os.path.join(out_dir, "gathered.npz"),
                  reward=np.stack([r[0] for r in rec]), term=np.stack([r[1] for r in rec]),
                  trunc=np.stack([r[2] for r in rec]), obs=np.stack([r[3] for r in rec]))
     dist.barrier()
     dist.destroy_process_group()
+
+
+class _SlotEnv:
+    """The return-slot interface of BatchedTradingEnv (return_slots, return_slot,
+    return_block, packed_returns) over the oracle, for the ReturnPipeline logic on CPU."""
+
+    def __init__(self, ora, slots):
+        self.ora, self.return_slots = ora, slots
+        self.n = ora.cfg.n_envs
+        self._packed_all = torch.zeros((slots, 6 * self.n), dtype=torch.uint8)
+        self._ret_slot = slots - 1
+
+    @property
+    def return_slot(self):
+        return (self._ret_slot + 1) % self.return_slots
+
+    def return_block(self, first, count):
+        return self._packed_all[first:first + count]
+
+    def step(self, a):
+        from gym_trading_env_amd.distributed import pack_returns
+        self._ret_slot = self.return_slot
+        self.ora.step(a)
+        self.packed_returns = pack_returns(
+            torch.from_numpy(self.ora.reward.copy()), torch.from_numpy(self.ora.terminated.copy()).bool(),
+            torch.from_numpy(self.ora.truncated.copy()).bool(), out=self._packed_all[self._ret_slot])
+
+
+def _block_worker(rank, world, port, out_dir, block, depth, steps):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gym_trading_env_amd.config import make_config
+    from gym_trading_env_amd.distributed import ReturnGather, ReturnPipeline, shard_range
+    from oracle import oracle
+    first, n = shard_range(G, world, rank)
+    ora = oracle.OracleEnv(make_config(n_envs=n, n_static=3, env_id_base=first, **KW), [_data()])
+    ora.reset()
+    env = _SlotEnv(ora, block * depth)
+    pipe = ReturnPipeline(env, ReturnGather(n, "cpu", depth=depth, block=block), block, depth)
+    actions = np.random.default_rng(5).integers(-1, 3, (steps, G)).astype(np.int32)
+    rows = []  # gathered (reward, term, trunc) per step, in step order
+    handles = []
+
+    def collect(h, count):
+        reward, term, trunc = h.wait()
+        if block == 1:
+            reward, term, trunc = reward[:, None], term[:, None], trunc[:, None]
+        for j in range(count):
+            rows.append((reward[:, j].reshape(-1).numpy().copy(), term[:, j].reshape(-1).numpy().copy(),
+                         trunc[:, j].reshape(-1).numpy().copy()))
+
+    for k in range(steps):
+        pipe.before_step()
+        env.step(actions[k, first:first + n])
+        h = pipe.after_step()
+        if h is not None:
+            handles.append(h)
+        if len(handles) == depth:  # consume as late as the rotation allows
+            collect(handles.pop(0), block)
+    for h in handles:
+        collect(h, block)
+    tail = pipe.flush()
+    if tail is not None:
+        collect(tail, steps % block)
+    assert len(rows) == steps
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "blocks.npz"), reward=np.stack([r[0] for r in rows]),
+                 term=np.stack([r[1] for r in rows]), trunc=np.stack([r[2] for r in rows]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("block,depth,steps", [(4, 2, 30), (1, 3, 20), (8, 2, 16)])
+def test_block_pipeline_two_ranks_equals_unsharded(tmp_path, oracle_mod, block, depth, steps):
+    """ReturnPipeline: returns gathered a block at a time, `depth` blocks in rotation, handles
+    consumed as late as allowed, unfinished block flushed — equals the unsharded run."""
+    from gym_trading_env_amd.config import make_config
+    port = 29850 + os.getpid() % 100 + block
+    mp.spawn(_block_worker, args=(2, port, str(tmp_path), block, depth, steps), nprocs=2, join=True)
+    got = np.load(tmp_path / "blocks.npz")
+    env = oracle_mod.OracleEnv(make_config(n_envs=G, n_static=3, env_id_base=0, **KW), [_data()])
+    env.reset()
+    actions = np.random.default_rng(5).integers(-1, 3, (steps, G)).astype(np.int32)
+    for k in range(steps):
+        env.step(actions[k])
+        np.testing.assert_array_equal(got["reward"][k], env.reward)
+        np.testing.assert_array_equal(got["term"][k], env.terminated.astype(bool))
+        np.testing.assert_array_equal(got["trunc"][k], env.truncated.astype(bool))
 
 
 def test_shard_range_partitions_all_envs():

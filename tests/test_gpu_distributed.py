@@ -24,7 +24,7 @@ def test_sharded_env_single_rank_nccl(oracle_mod):
         feat = rng.normal(0, 1, (T, Fs)).astype(np.float32)
         kw = dict(positions=[-1, 0, 1], windows=5, trading_fees=1e-4, max_episode_duration=20,
                   autoreset="next_step", seed=4)
-        env = ShardedTradingEnv((feat, close), G, gather_obs=True, **kw)
+        env = ShardedTradingEnv((feat, close), G, gather_obs=True, pipeline=3, **kw)
         full = np.zeros((T, Fs + 2), np.float32)
         full[:, :Fs] = feat
         ora = oracle_mod.OracleEnv(env.env.cfg, [(full, close)])
@@ -39,9 +39,88 @@ def test_sharded_env_single_rank_nccl(oracle_mod):
             np.testing.assert_array_equal(reward.cpu().numpy().reshape(-1), ora.reward)
             np.testing.assert_array_equal(term.cpu().numpy().reshape(-1), ora.terminated.astype(bool))
             np.testing.assert_array_equal(trunc.cpu().numpy().reshape(-1), ora.truncated.astype(bool))
+        # pipelined: up to 2 all-gathers in flight on RCCL's stream while the next steps run
+        # (3 rotating return buffers); each handle is consumed two steps late
+        handles, expect = [], []
+        for k in range(40):
+            a = rng.integers(-1, 3, G).astype(np.int32)
+            _, pending, _ = env.step_async(torch.from_numpy(a).cuda())
+            ora.step(a)
+            handles.append(pending)
+            expect.append((ora.reward.copy(), ora.terminated.astype(bool), ora.truncated.astype(bool)))
+            if k >= 2:
+                reward, term, trunc = handles[k - 2].wait()
+                np.testing.assert_array_equal(reward.cpu().numpy().reshape(-1), expect[k - 2][0])
+                np.testing.assert_array_equal(term.cpu().numpy().reshape(-1), expect[k - 2][1])
+                np.testing.assert_array_equal(trunc.cpu().numpy().reshape(-1), expect[k - 2][2])
+        env.drain()
+        env.close()
+        # block form: one all-gather per 4 steps, 2 blocks in rotation
+        env = ShardedTradingEnv((feat, close), G, pipeline=2, block=4, **kw)
+        ora = oracle_mod.OracleEnv(env.env.cfg, [(full, close)])
+        env.reset()
+        ora.reset()
+        expect, seen = [], 0
+        for k in range(22):
+            a = rng.integers(-1, 3, G).astype(np.int32)
+            obs, pending, _ = env.step_async(torch.from_numpy(a).cuda())
+            ora.step(a)
+            np.testing.assert_array_equal(obs.cpu().numpy(), ora.obs)
+            expect.append((ora.reward.copy(), ora.terminated.astype(bool)))
+            assert (pending is not None) == (k % 4 == 3)
+            if pending is not None:
+                reward, term, _ = pending.wait()
+                assert reward.shape == (1, 4, G)
+                for j in range(4):
+                    np.testing.assert_array_equal(reward[0, j].cpu().numpy(), expect[k - 3 + j][0])
+                    np.testing.assert_array_equal(term[0, j].cpu().numpy(), expect[k - 3 + j][1])
+                seen += 4
+        tail = env._pipe.flush()  # steps 20, 21: the unfinished block
+        reward, _, _ = tail.wait()
+        np.testing.assert_array_equal(reward[0, 0].cpu().numpy(), expect[20][0])
+        np.testing.assert_array_equal(reward[0, 1].cpu().numpy(), expect[21][0])
+        assert seen == 20
         env.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_return_slots_keep_older_returns_intact(oracle_mod):
+    """return_slots=3: step t writes packed buffer t % 3; the buffers of steps t-1 and t-2
+    still hold those steps' returns (what an all-gather in flight reads)."""
+    import torch
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    rng = np.random.default_rng(2)
+    T, Fs, N = 400, 3, 700
+    close = 100 * np.exp(np.cumsum(rng.normal(0, 2e-2, T)))
+    feat = rng.normal(0, 1, (T, Fs)).astype(np.float32)
+    kw = dict(positions=[-1, 0, 1], windows=None, trading_fees=1e-3, borrow_interest_rate=1e-4,
+              max_episode_duration=15, autoreset="same_step", seed=9)
+    env = BatchedTradingEnv((feat, close), num_envs=N, return_slots=3, **kw)
+    full = np.zeros((T, Fs + 2), np.float32)
+    full[:, :Fs] = feat
+    ora = oracle_mod.OracleEnv(env.cfg, [(full, close)])
+    env.reset()
+    ora.reset()
+    kept = []
+    for k in range(25):
+        a = rng.integers(-1, 3, N).astype(np.int32)
+        _, reward, term, trunc, _ = env.step(torch.from_numpy(a).cuda())
+        ora.step(a)
+        kept.append((env.packed_returns, reward, term, trunc, ora.reward.copy(),
+                     ora.terminated.astype(bool), ora.truncated.astype(bool)))
+        for packed, r, t, u, er, et, eu in kept[-3:]:  # this step and the two before it
+            np.testing.assert_array_equal(r.cpu().numpy(), er)
+            np.testing.assert_array_equal(t.cpu().numpy(), et)
+            np.testing.assert_array_equal(u.cpu().numpy(), eu)
+            np.testing.assert_array_equal(packed[:4 * N].view(torch.float32).cpu().numpy(), er)
+        np.testing.assert_array_equal(env.read_output("reward"), ora.reward)
+        np.testing.assert_array_equal(env.read_output("terminated").astype(bool),
+                                      ora.terminated.astype(bool))
+    assert len({k[0].data_ptr() for k in kept}) == 3
+    with pytest.raises(ValueError):
+        BatchedTradingEnv((feat, close), num_envs=N, return_slots=2, output="numpy", **kw)
+    env.close()
 
 
 def _rank_main(rank, world, port, out_dir):
@@ -61,15 +140,30 @@ def _rank_main(rank, world, port, out_dir):
         feat = rng.normal(0, 1, (T, Fs)).astype(np.float32)
         kw = dict(positions=[-1, 0, 1], windows=5, trading_fees=1e-4, max_episode_duration=20,
                   autoreset="next_step", seed=4)
-        env = ShardedTradingEnv((feat, close), G, device=0, gather_obs=True, **kw)
+        env = ShardedTradingEnv((feat, close), G, device=0, gather_obs=True, pipeline=2, **kw)
         env.reset()
         acts = np.random.default_rng(1).integers(-1, 3, (30, G)).astype(np.int32)
         rec = []
+        prev = None
         for k in range(30):
             a = torch.from_numpy(acts[k, env.first:env.first + env.n_local]).cuda()
-            obs, reward, term, trunc, _ = env.step(a)
-            rec.append((obs.cpu().numpy().copy(), reward.cpu().numpy().reshape(-1).copy(),
-                        term.cpu().numpy().reshape(-1).copy(), trunc.cpu().numpy().reshape(-1).copy()))
+            if k < 15:
+                obs, reward, term, trunc, _ = env.step(a)
+                rec.append((obs.cpu().numpy().copy(), reward.cpu().numpy().reshape(-1).copy(),
+                            term.cpu().numpy().reshape(-1).copy(),
+                            trunc.cpu().numpy().reshape(-1).copy()))
+                continue
+            obs, pending, _ = env.step_async(a)  # returns consumed one step late
+            obs = env.returns.gather_obs(obs).cpu().numpy().copy()
+            if prev is not None:
+                reward, term, trunc = prev[0].wait()
+                rec.append((prev[1], reward.cpu().numpy().reshape(-1).copy(),
+                            term.cpu().numpy().reshape(-1).copy(),
+                            trunc.cpu().numpy().reshape(-1).copy()))
+            prev = (pending, obs)
+        reward, term, trunc = prev[0].wait()
+        rec.append((prev[1], reward.cpu().numpy().reshape(-1).copy(),
+                    term.cpu().numpy().reshape(-1).copy(), trunc.cpu().numpy().reshape(-1).copy()))
         if rank == 0:
             np.savez(os.path.join(out_dir, "g.npz"), obs=np.stack([r[0] for r in rec]),
                      reward=np.stack([r[1] for r in rec]), term=np.stack([r[2] for r in rec]),
