@@ -284,9 +284,26 @@ def main():
             if os.path.exists(rp):
                 try:
                     ref = json.load(open(rp))
-                    out["cpu_baseline"]["reference_python"] = {
-                        "where": ref["where"], "cpu": ref["cpu"], "cores": ref["cores"],
-                        "env_steps_per_s": ref["shapes"].get(args.workload)}
+                    rpy = {"where": ref["where"], "cpu": ref["cpu"], "cores": ref["cores"],
+                           "env_steps_per_s": ref["shapes"].get(args.workload)}
+                    # the build's own interpreter-bound per-env loop (oracle/py_loop.py) was timed
+                    # there next to the reference and is timed here now, on one core: the ratio
+                    # rescales the reference's own figure to this box (an estimate, labelled so)
+                    here = ref.get("python_loop_c3_steps_per_s_1_process")
+                    one = (ref["shapes"].get(args.workload) or {}).get("steps_per_s_1_process")
+                    if here and one:
+                        from oracle.py_loop import time_loop
+                        rate, n, el = time_loop(seconds=2.0)
+                        cores = out["cpu_baseline"]["cores"]
+                        rpy["python_loop"] = {"env_steps_per_s_this_box_1_core": rate,
+                                              "env_steps_per_s_there_1_core": here,
+                                              "sample": f"{n} steps, {el:.1f} s, config-3-shaped env"}
+                        rpy["estimated_on_this_box"] = {
+                            "env_steps_per_s_1_core": one * rate / here, "cores": cores,
+                            "env_steps_per_s_all_cores": one * rate / here * cores,
+                            "how": "reference timing there x (python_loop here / python_loop there), "
+                                   "one process per core"}
+                    out["cpu_baseline"]["reference_python"] = rpy
                 except Exception:
                     pass
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -48,6 +48,87 @@ def test_oracle_tiled_and_threaded_equals_single(oracle_mod):
     replay.replay(a, g, tile=5)
 
 
+class PyLoopAdapter:
+    """oracle/py_loop.py (one interpreter-bound Python object per env) behind the replay
+    interface: next-step auto-reset and injected draws are done here, as a user loop would."""
+
+    def __init__(self, g):
+        from oracle.py_loop import PyEnv
+        cfg = dict(g["cfg"])
+        rf = cfg.get("reward_function", "basic_reward_function")
+        reward = ("log",) if isinstance(rf, str) else (rf[0].split("_")[0],) + tuple(rf[1:])
+        dyn = tuple({"position": "position", "real_position": "real"}[d] for d in
+                    cfg.get("dynamic_feature_functions", ["position", "real_position"]))
+        self.positions = cfg["positions"]
+        self.autoreset = bool((g["op"][1:] == 0).any())
+        E = g["op"].shape[1]
+        feat, close = g["datasets"][0][:2]
+        self.envs = []
+        for _ in range(E):
+            table = np.zeros((feat.shape[0], feat.shape[1] + len(dyn)), np.float32)
+            table[:, :feat.shape[1]] = feat
+            self.envs.append(PyEnv(table, close, self.positions, windows=cfg["windows"],
+                                   trading_fees=cfg["trading_fees"],
+                                   borrow_interest_rate=cfg["borrow_interest_rate"],
+                                   portfolio_initial_value=cfg["portfolio_initial_value"],
+                                   initial_position=cfg["initial_position"],
+                                   max_episode_duration=cfg["max_episode_duration"], dyn=dyn,
+                                   reward=reward, persist=bool(cfg.get("dyn_persist", False))))
+        self.q, self.head = None, [0] * E
+        self._obs = [None] * E
+
+    def set_autoreset_injection(self, idx, pos, ds):
+        self.q = (idx, pos)
+
+    def reset(self, mask, idx, pos, ds):
+        for e, env in enumerate(self.envs):
+            self._obs[e] = env.reset(int(idx[e]), int(pos[e])).copy()
+
+    def step(self, actions):
+        for e, env in enumerate(self.envs):
+            if env.ended and self.autoreset:
+                j = self.head[e]
+                self.head[e] += 1
+                self._obs[e] = env.reset(int(self.q[0][e, j]), int(self.q[1][e, j])).copy()
+            else:
+                self._obs[e] = env.step(int(actions[e]))[0].copy()
+
+    obs = lambda s: np.stack(s._obs)
+    reward64 = lambda s: np.array([float(e.reward) for e in s.envs])
+    terminated = lambda s: np.array([e.done for e in s.envs])
+    truncated = lambda s: np.array([e.truncated for e in s.envs])
+
+    def state(self):
+        col = lambda f, dt: np.array([f(e) for e in self.envs], dt)
+        return {"idx": col(lambda e: e.idx, np.int32), "step": col(lambda e: e.step_no, np.int32),
+                "position_index": col(lambda e: self.positions.index(e.position), np.int32),
+                "dataset_index": col(lambda e: 0, np.int32),
+                "asset": col(lambda e: e.book.asset, np.float64),
+                "fiat": col(lambda e: e.book.fiat, np.float64),
+                "interest_asset": col(lambda e: e.book.ia, np.float64),
+                "interest_fiat": col(lambda e: e.book.ifi, np.float64),
+                "portfolio_valuation": col(lambda e: e.log[-1]["portfolio_valuation"], np.float64),
+                "real_position": col(lambda e: e.log[-1]["real_position"], np.float64)}
+
+
+def _py_loop_traces():
+    out = []
+    for name in replay.golden_names():
+        g = replay.load(name)
+        if len(g["datasets"]) == 1 and "lo_pos" not in g:
+            out.append(name)
+    return out
+
+
+@pytest.mark.parametrize("name", _py_loop_traces())
+def test_python_loop_matches_reference_trace(name):
+    """The second restatement (pure-Python, one object per env) against the reference's
+    vectors: state bit-exact, as for the C oracle."""
+    g = replay.load(name)
+    worst = replay.replay(PyLoopAdapter(g), g, rtol=1e-12)
+    assert worst == 0.0
+
+
 # SURVEY §8c: captured from the reference by import; TargetPortfolio(0, 1000, 100)
 KAT = [
     (-1, 100, 101, -9.990009990009991, 1998.001998001998, 0.009990009990009992, 0.0, 988.0019980019979, -1.0222651391823985),

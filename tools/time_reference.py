@@ -57,6 +57,14 @@ def main():
             many = pool.map(_run, [(shape, 4.0)] * cores)
         out["shapes"][shape] = {"steps_per_s_1_process": one, f"steps_per_s_{cores}_processes": sum(many)}
         print(shape, out["shapes"][shape], flush=True)
+    # the build's own interpreter-bound loop (oracle/py_loop.py), timed HERE right after the
+    # reference: bench.py times the same loop on the GPU box and uses the ratio to rescale
+    # the reference's numbers to that box's cores
+    sys.path.insert(0, ROOT)
+    from oracle.py_loop import time_loop
+    rates = [time_loop(seconds=3.0)[0] for _ in range(3)]
+    out["python_loop_c3_steps_per_s_1_process"] = float(np.median(rates))
+    print("py_loop c3", rates, flush=True)
     with open(os.path.join(ROOT, "profiles", "reference_cpu_timing.json"), "w") as f:
         json.dump(out, f, indent=1)
 
