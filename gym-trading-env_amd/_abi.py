@@ -81,6 +81,12 @@ class GteConfig(C.Structure):
     ]
 
 
+class GteRolloutBufs(C.Structure):
+    """struct gte_rollout_bufs (include/gte.h): optional per-step result arrays."""
+    _fields_ = [("obs", C.c_void_p), ("reward", C.c_void_p), ("reward64", C.c_void_p),
+                ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("valuation", C.c_void_p)]
+
+
 class GteOutputs(C.Structure):
     """struct gte_outputs: device pointers, kept as integers."""
 
@@ -145,6 +151,7 @@ SYMBOLS = {
     "gte_get_outputs": (C.c_int, [C.c_void_p, _P(GteOutputs)]),
     "gte_get_state": (C.c_int, [C.c_void_p, _P(GteStateView)]),
     "gte_bind_outputs": (C.c_int, [C.c_void_p, _P(GteOutputs)]),
+    "gte_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, _P(GteRolloutBufs)]),
     "gte_bind_returns": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gte_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gte_use_own_stream": (C.c_int, [C.c_void_p]),

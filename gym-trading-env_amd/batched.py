@@ -507,6 +507,50 @@ class BatchedTradingEnv(_VectorEnvBase):
         obs, reward, term, trunc = self._results()
         return obs, reward, term, trunc, LazyInfo(self)
 
+    def rollout(self, actions, *, keep_obs=False, valuation=False, reward64=False):
+        """K consecutive step() calls for action sequences known in advance, in ONE launch
+        (`gte_rollout`: backtests of precomputed strategies, random-policy collection).
+
+        actions: int32 [K, N] (-1 = hold), a torch CUDA tensor or anything array-like.
+        Returns a dict of device tensors: reward f32 [K, N], terminated / truncated bool
+        [K, N], obs — [K, N, *obs_shape] with keep_obs=True, else the observation after the
+        last step [N, *obs_shape] —, and on request valuation f64 [K, N] (portfolio value
+        after each step) and reward64.  State and results equal K single steps exactly."""
+        torch = self._torch
+        if torch is None:
+            raise ValueError("rollout needs output='torch'")
+        dev = self._t["obs"].device
+        if not (isinstance(actions, torch.Tensor) and actions.is_cuda):
+            a = np.asarray([[-1 if x is None else x for x in row] for row in actions]
+                           if isinstance(actions, (list, tuple)) else actions, dtype=np.int32)
+            if a.size and (a.max() >= len(self.positions) or a.min() < -1):
+                raise IndexError("list index out of range")
+            actions = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        actions = actions.to(torch.int32).contiguous()
+        if actions.dim() != 2 or actions.shape[1] != self.num_envs or actions.shape[0] < 1:
+            raise ValueError(f"expected actions of shape (K, {self.num_envs})")
+        K, N = int(actions.shape[0]), self.num_envs
+        with torch.cuda.device(dev):
+            out = {"reward": torch.empty((K, N), dtype=torch.float32, device=dev),
+                   "terminated": torch.empty((K, N), dtype=torch.bool, device=dev),
+                   "truncated": torch.empty((K, N), dtype=torch.bool, device=dev)}
+            if keep_obs:
+                out["obs"] = torch.empty((K, N) + self.obs_shape, dtype=torch.float32, device=dev)
+            if valuation:
+                out["valuation"] = torch.empty((K, N), dtype=torch.float64, device=dev)
+            if reward64:
+                out["reward64"] = torch.empty((K, N), dtype=torch.float64, device=dev)
+        b = _abi.GteRolloutBufs()
+        for k, t in out.items():
+            setattr(b, k, t.data_ptr())
+        self._keep = (actions, out)  # alive until the launch has consumed them
+        _abi.check(self._lib, self._lib.gte_rollout(self._h, C.c_void_p(actions.data_ptr()), K,
+                                                    C.byref(b)))
+        self._epoch += 1
+        if not keep_obs:
+            out["obs"] = self._t["obs"]
+        return out
+
     # -- misc ---------------------------------------------------------------------------
     def synchronize(self):
         _abi.check(self._lib, self._lib.gte_synchronize(self._h))

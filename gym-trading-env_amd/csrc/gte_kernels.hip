@@ -260,9 +260,12 @@ struct OldState {  // what phase A started from (for the prediction check)
   int32_t idx, dsi, start, needs_reset;
 };
 
+// compact: add the envs whose episode ended to the terminal list (off for the inner steps
+// of a fused rollout, which keeps per-step flags instead); pv_out: the valuation after the step.
 template <int MODE>
 __device__ inline void phase_a(const Params& p, int e, bool active, int lane, ObsJob& job,
-                               OldState* old = nullptr, FinalJob* fin = nullptr) {
+                               OldState* old = nullptr, FinalJob* fin = nullptr,
+                               bool compact = true, double* pv_out = nullptr) {
   if (fin) fin->flags = 0;
   job.src = nullptr; job.slot0 = 0; job.n_zero = 0; job.idx = 0; job.flags = 0;
 #pragma unroll
@@ -311,8 +314,13 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
         // no auto-reset and no row left: the reference raises IndexError (:239);
         // the batch leaves such an env frozen, flags still raised
         p.reward[e] = 0.0f; p.reward64[e] = 0.0;
+        // its flags stay raised (rewritten, not relied upon: a rollout writes every step's
+        // flags to a fresh row): the valuation has not moved since the 0.7 test (:246), and
+        // being on the last row is the truncation rule itself (:248)
+        p.terminated[e] = (s.pv / p.V0) <= 0.7 ? 1 : 0;
+        p.truncated[e] = 1;
         stepped = false;
-        ended = true;  // its flags stay raised, so it stays in the terminal list
+        ended = true;  // so it stays in the terminal list
       }
     }
     if (stepped) {
@@ -368,6 +376,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
       }
     }
     GTE_STAMP(4);  // state machine done, outputs issued
+    if (pv_out) *pv_out = s.pv;
     store_state(p, e, s);
     make_job(p, e, s, fresh, job);
     GTE_STAMP(5);  // record, ring and job stores done
@@ -375,7 +384,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
 
   // terminal-mask compaction: one atomic per wave, ids in lane order within a wave
   const unsigned long long m = __ballot(ended);
-  if (m != 0ull) {
+  if (compact && m != 0ull) {
     const int cnt = __popcll(m);
     const int leader = __ffsll((long long)m) - 1;
     int base = 0;
@@ -580,16 +589,19 @@ __device__ inline void patch_dynamic(const Params& p, const WgLds& L, vec_t& v, 
 // contiguous, fully used bytes whatever the window size (also when an env's window is
 // smaller than one wave instruction, e.g. windows=None).  The env differs per lane:
 // its job is read from LDS.  U independent loads are in flight per lane.
+// [k_lo, k_hi): the part of the index space to copy (a chunk claimed by the rollout kernel;
+// everything by default).
 template <int VEC, int NT, int STAGE, int U>
 __device__ inline void phase_b(const Params& p, const WgLds& L, int s_first,
-                               int n_env, int lane, uint64_t vpe_magic, uint64_t fv_magic) {
+                               int n_env, int lane, uint64_t vpe_magic, uint64_t fv_magic,
+                               uint32_t k_lo = 0u, uint32_t k_hi = 0xFFFFFFFFu) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
   const uint32_t V = (uint32_t)(p.W * p.Fobs);
   const uint32_t VPE = V / VEC;                // vectors per env
   const uint32_t FV = (uint32_t)p.Fobs / VEC;  // vectors per row
-  const uint32_t total = (uint32_t)n_env * VPE;
+  const uint32_t total = min((uint32_t)n_env * VPE, k_hi);
 
-  for (uint32_t k0 = 0; k0 < total; k0 += 64u * U) {
+  for (uint32_t k0 = k_lo; k0 < total; k0 += 64u * U) {
     vec_t v[U];
     uint32_t jj[U], ee[U], mm[U];
     int32_t env[U];

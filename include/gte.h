@@ -118,7 +118,11 @@ typedef struct gte_config {
                                1-3 gather predicted windows during phase A)
                                instead of the classic one (csrc/gte_kernels.hip),
                                64 = launch the shared-TU instantiation of the hot
-                               kernel instead of the isolated one (gte_hot.hip)   */
+                               kernel instead of the isolated one (gte_hot.hip),
+                               128 = gte_rollout runs as one launch per step even
+                               where the fused kernel applies, 256 = gte_rollout
+                               uses the fused kernel also for per-step observations
+                               of big batches (where it measures slower)           */
   int32_t debug_flags;      /* timing ablations only (results become wrong):
                                1 = skip the observation gather, 2 = skip the
                                dynamic-column patch, 8 = skip the window loads
@@ -249,6 +253,29 @@ int gte_get_log(gte_env* env, gte_log_view* out);
 int gte_read_log(gte_env* env, int32_t env_id, int32_t n, int32_t* idx, int32_t* step,
                  int32_t* position_index, int32_t* dataset_index, double* portfolio_valuation,
                  double* real_position, double* reward, uint8_t* flags, int32_t* n_out);
+
+/* Per-step results of gte_rollout, all device pointers, all optional (NULL = not kept).
+ * Row k holds what the k-th gte_step of the sequence would have produced. */
+typedef struct gte_rollout_bufs {
+  float* obs;           /* f32 [K][N][W][F_obs]; NULL: only the last step's observation is
+                           produced, in the env's own obs buffer (gte_get_outputs) */
+  float* reward;        /* f32 [K][N] */
+  double* reward64;     /* f64 [K][N] */
+  uint8_t* terminated;  /* u8  [K][N] */
+  uint8_t* truncated;   /* u8  [K][N] */
+  double* valuation;    /* f64 [K][N]: portfolio_valuation after each step (environments.py:241) */
+} gte_rollout_bufs;
+
+/* n_steps consecutive TradingEnv.step calls (environments.py:233-272) for action sequences
+ * known in advance — `actions` is a DEVICE pointer to int32 [n_steps][N], -1 = hold — fused
+ * into one launch (gte_rollout.hip).  State, auto-resets, injected draws, limit-order fills and
+ * the results are exactly those of n_steps gte_step calls; afterwards the env's own reward /
+ * flag buffers and terminal list describe the last step, and its obs buffer holds the last
+ * observation unless bufs->obs was given (then that is row n_steps-1 of bufs->obs).  Shapes the
+ * fused kernel does not cover (dyn_persist, final_obs, log_steps, scalar-vector layouts), and
+ * per-step observations of >= 64 MB per step (HBM-write bound either way, measured faster as
+ * separate launches), run as n_steps launches of the step kernel with the same results. */
+int gte_rollout(gte_env* env, const int32_t* actions, int32_t n_steps, const gte_rollout_bufs* bufs);
 
 /* Where the results of the last gte_step / gte_reset live (device pointers). */
 int gte_get_outputs(gte_env* env, gte_outputs* out);

@@ -83,3 +83,40 @@ def test_config4_total_size_on_one_gpu_vs_oracle(oracle_mod):
     ds = [_synthetic(1234, 100_000, 30, sigma=1e-3)]
     _compare_with_oracle(oracle_mod, ds, n_envs=262_144, steps=12, seed=14, check_every=6,
                          max_episode_duration=7, **C3)
+
+
+def test_config3_full_size_rollout_paths_agree():
+    """65 536 envs x obs (20, 32): a rollout that keeps every observation (168 MB per step:
+    runs as separate launches), one that keeps only the last (fused kernel), one forced through
+    the fused kernel with observations (kernel_variant 256) and plain single steps must agree
+    bit for bit, episodes ending and restarting on the way."""
+    import torch
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    ds = _synthetic(1234, 100_000, 30, sigma=1e-3)
+    N, K = 65_536, 12
+    kw = dict(num_envs=N, seed=21, max_episode_duration=7, **C3)
+    envs = [BatchedTradingEnv(ds, **kw), BatchedTradingEnv(ds, **kw),
+            BatchedTradingEnv(ds, kernel_variant=256, **kw), BatchedTradingEnv(ds, **kw)]
+    for e in envs:
+        e.reset()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3)
+    acts = torch.randint(-1, 3, (K, N), dtype=torch.int32, device="cuda", generator=gen)
+    full = envs[0].rollout(acts, keep_obs=True)
+    lean = envs[1].rollout(acts, keep_obs=False, valuation=True)
+    forced = envs[2].rollout(acts, keep_obs=True)
+    for k in range(K):
+        obs, reward, term, trunc, _ = envs[3].step(acts[k])
+        for out in (full, lean, forced):
+            assert torch.equal(out["reward"][k], reward)
+            assert torch.equal(out["terminated"][k], term) and torch.equal(out["truncated"][k], trunc)
+        assert torch.equal(full["obs"][k], obs) and torch.equal(forced["obs"][k], obs)
+    assert torch.equal(lean["obs"], obs)
+    assert int(full["truncated"].sum()) >= N  # every env finished an episode and restarted
+    for f in ("idx", "step", "episode", "asset", "fiat", "portfolio_valuation"):
+        ref = envs[3].state(f)
+        for e in envs[:3]:
+            np.testing.assert_array_equal(e.state(f), ref, err_msg=f)
+    np.testing.assert_array_equal(lean["valuation"][-1].cpu().numpy(), envs[3].state("portfolio_valuation"))
+    for e in envs:
+        e.close()
