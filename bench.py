@@ -15,9 +15,12 @@ this shape); `cpu_baseline` is the oracle's C restatement (oracle/, a "port")
 timed on this box's host cores on a bounded sample of the same workload.
 
 Multi-GPU (torchrun, one rank per GPU): envs shard with no data-path collective
-except the per-step RCCL all-gather of (reward, terminated, truncated) — 6 bytes
-per env — which is what the north star names; --gather-obs adds the observation
-all-gather (xGMI-bound, SURVEY §7 hard part 7).  Weak scaling: 65 536 envs/GPU.
+except the RCCL all-gather of the returns (reward, terminated, truncated: 6 bytes
+per env and step), which is what the north star names.  Every step's returns cross
+xGMI inside the timed region, a --gather-every (16) step block at a time on RCCL's
+stream while the following steps run (DESIGN.md §6 has the per-step alternatives
+measured); --gather-obs adds the observation all-gather (xGMI-bound, SURVEY §7
+hard part 7).  Weak scaling: 65 536 envs/GPU.
 """
 from __future__ import annotations
 
@@ -180,21 +183,23 @@ def main():
     # configs 2-4: ONE dataset replicated on every rank; config 5: symbols partitioned by rank
     data = [synthetic_dataset((rank * D + d) if D > 1 else 0, wl["T"], wl["n_static"])
             for d in range(D)]
+    tuning = dict(envs_per_wave=args.epw, kernel_variant=args.variant,
+                  affinity_period=args.affinity)
+    if args.nt >= 0:
+        tuning["nontemporal_obs"] = args.nt
     env = BatchedTradingEnv(data if D > 1 else data[0], num_envs=N, seed=20240607,
-                            env_id_base=rank * N,
-                            device=local_rank, output="torch", envs_per_wave=args.epw,
-                            **({} if args.nt < 0 else {'nontemporal_obs': args.nt}), kernel_variant=args.variant, affinity_period=args.affinity,
-                            return_slots=(max(1, args.gather_depth) * block) if use_dist else 1,
-                            **env_kwargs(wl))
+                            env_id_base=rank * N, device=local_rank, output="torch",
+                            return_slots=depth * block if use_dist else 1,
+                            **tuning, **env_kwargs(wl))
     gen = torch.Generator(device=dev)
     gen.manual_seed(99 + rank)
     n_rows = 64
     actions = torch.randint(0, 3, (n_rows, N), dtype=torch.int32, device=dev, generator=gen)
     env.reset()
 
-    # per-step return of a sharded run: one RCCL all-gather of the packed
-    # (reward f32 | terminated u8 | truncated u8) records, 6 bytes per env, which the
-    # kernel writes directly in that layout (env.packed_returns)
+    # the return of a sharded run: RCCL all-gather of the packed (reward f32 | terminated u8 |
+    # truncated u8) records, 6 bytes per env and step, which the kernel writes directly in
+    # that layout; by default a 16-step block at a time, overlapping the following steps
     returns = pipe = None
     if use_dist:
         from gym_trading_env_amd.distributed import ReturnGather, ReturnPipeline
