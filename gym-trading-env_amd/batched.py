@@ -482,6 +482,12 @@ class BatchedTradingEnv(_VectorEnvBase):
         actions: position indices, shape (N,); -1 (or None entries) = hold (:234).
         A torch int32 CUDA tensor is used in place; anything else goes through a
         host->device copy."""
+        self._launch_step(actions)
+        obs, reward, term, trunc = self._results()
+        return obs, reward, term, trunc, LazyInfo(self)
+
+    def _launch_step(self, actions):
+        """The launch half of step(): nothing is copied back."""
         torch = self._torch
         if torch is not None and isinstance(actions, torch.Tensor) and actions.is_cuda:
             if actions.dtype != torch.int32 or not actions.is_contiguous():
@@ -504,8 +510,15 @@ class BatchedTradingEnv(_VectorEnvBase):
                 raise IndexError("list index out of range")  # positions[position_index] (:234)
             _abi.check(self._lib, self._lib.gte_step(self._h, a.ctypes.data, 0))
         self._epoch += 1
-        obs, reward, term, trunc = self._results()
-        return obs, reward, term, trunc, LazyInfo(self)
+
+    def read_env(self, env_index: int = 0, with_obs: bool = True):
+        """(GteEnvSnapshot, obs ndarray | None) of ONE env after the last step/reset: state,
+        returns and observation in a single device->host transfer (`gte_read_env`)."""
+        snap = _abi.GteEnvSnapshot()
+        obs = np.empty(self.obs_shape, np.float32) if with_obs else None
+        _abi.check(self._lib, self._lib.gte_read_env(
+            self._h, int(env_index), C.byref(snap), obs.ctypes.data if with_obs else None))
+        return snap, obs
 
     def rollout(self, actions, *, keep_obs=False, valuation=False, reward64=False):
         """K consecutive step() calls for action sequences known in advance, in ONE launch

@@ -46,6 +46,9 @@ struct LogArrays {
 hipError_t launch_log(const EnvRec* rec, const double* reward64, const uint8_t* term,
                       const uint8_t* trunc, int n, int64_t row_base, const LogArrays& o,
                       hipStream_t stream);
+hipError_t launch_snapshot(const EnvRec* rec, const double* reward64, const uint8_t* term,
+                           const uint8_t* trunc, const float* obs, int64_t obs_elems, int e,
+                           void* dst, float* dst_obs, hipStream_t stream);
 hipError_t launch_affinity_rebuild(const Params& p, int32_t* bins, int n_bins_per_ds,
                                    const int32_t* slot_of_rank, int32_t* perm_out,
                                    hipStream_t stream);
@@ -113,6 +116,7 @@ struct gte_env {
   gte::StateSoA soa = {};  // host-facing struct-of-arrays mirrors (gte_get_state)
   gte::LogArrays log = {}; // device trajectory log (cfg.log_steps rows per env)
   int64_t log_rows = 0;
+  void* h_snap = nullptr;  // pinned host memory for gte_read_env: snapshot + one observation
 };
 
 template <typename T>
@@ -733,6 +737,25 @@ int gte_bind_outputs(gte_env* E, const gte_outputs* b) {
   return GTE_OK;
 }
 
+static_assert(sizeof(gte_env_snapshot) == 96, "gte_env_snapshot layout");
+
+int gte_read_env(gte_env* E, int32_t e, gte_env_snapshot* out, float* obs) {
+  if (!E || !out) return fail(GTE_ERR_INVALID, "NULL argument");
+  if (!E->was_reset) return fail(GTE_ERR_STATE, "gte_read_env before gte_reset");
+  if (e < 0 || e >= E->p.N) return fail(GTE_ERR_INVALID, "env_index %d out of range", e);
+  HIPCHK(hipSetDevice(E->cfg.device));
+  const int64_t elems = (int64_t)E->p.W * E->p.Fobs;
+  if (!E->h_snap)  // pinned and mapped: the kernel writes host memory directly
+    HIPCHK(hipHostMalloc(&E->h_snap, 128 + sizeof(float) * (size_t)elems, hipHostMallocMapped));
+  float* h_obs = (float*)((char*)E->h_snap + 128);
+  HIPCHK(gte::launch_snapshot(E->p.rec, E->p.reward64, E->p.terminated, E->p.truncated, E->p.obs,
+                              elems, e, E->h_snap, obs ? h_obs : nullptr, E->stream));
+  HIPCHK(hipStreamSynchronize(E->stream));
+  memcpy(out, E->h_snap, sizeof(gte_env_snapshot));
+  if (obs) memcpy(obs, h_obs, sizeof(float) * (size_t)elems);
+  return GTE_OK;
+}
+
 int gte_bind_returns(gte_env* E, float* reward, uint8_t* terminated, uint8_t* truncated) {
   if (!E || !reward || !terminated || !truncated) return fail(GTE_ERR_INVALID, "NULL argument");
   // Params travel by value with every launch: later launches see the new pointers,
@@ -838,6 +861,7 @@ void gte_destroy(gte_env* E) {
   for (auto& v : E->ds_allocs)
     for (void* ptr : v)
       if (ptr) (void)hipFree(ptr);
+  if (E->h_snap) (void)hipHostFree(E->h_snap);
   if (E->ev0) (void)hipEventDestroy(E->ev0);
   if (E->ev1) (void)hipEventDestroy(E->ev1);
   if (E->own_stream) (void)hipStreamDestroy(E->own_stream);

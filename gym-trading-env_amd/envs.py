@@ -122,14 +122,16 @@ class TradingEnv(_EnvBase):
 
     # -- helpers -------------------------------------------------------------------------
     def _sync_state(self):
-        b = self._batch
-        self._idx = int(b.state("idx")[0])
-        self._step = int(b.state("step")[0])
-        self._position = self.positions[int(b.state("position_index")[0])]
-        self._portfolio_state = {k: float(b.state(k)[0]) for k in
-                                 ("asset", "fiat", "interest_asset", "interest_fiat")}
-        self._portfolio_value = float(b.state("portfolio_valuation")[0])
-        self._real_position = float(b.state("real_position")[0])
+        """One transfer per step/reset: state, returns and observation of the env."""
+        snap, self._last_obs = self._batch.read_env(0)
+        self._idx, self._step = snap.idx, snap.step
+        self._position = self.positions[snap.position_index]
+        self._portfolio_state = {"asset": snap.asset, "fiat": snap.fiat,
+                                 "interest_asset": snap.interest_asset,
+                                 "interest_fiat": snap.interest_fiat}
+        self._portfolio_value = snap.portfolio_valuation
+        self._real_position = snap.real_position
+        self._snap = snap
 
     def _distribution(self):  # Portfolio.get_portfolio_distribution, portfolio.py:49-57
         s = self._portfolio_state
@@ -154,7 +156,7 @@ class TradingEnv(_EnvBase):
         return self.df.iloc[self._idx + delta]
 
     def _obs(self):
-        return self._batch.read_output("obs")[0]
+        return self._last_obs
 
     # -- reset (:163-199) ----------------------------------------------------------------
     def reset(self, seed=None, options=None, **kwargs):
@@ -194,15 +196,14 @@ class TradingEnv(_EnvBase):
         if self._idx + 1 >= len(self._price_array):
             raise IndexError(f"index {self._idx + 1} is out of bounds for axis 0 with size "
                              f"{len(self._price_array)}")  # :239 past the last row
-        self._batch.step([-1 if position_index is None else int(position_index)])
+        self._batch._launch_step([-1 if position_index is None else int(position_index)])
         self._sync_state()
-        done = bool(self._batch.read_output("terminated")[0])
-        truncated = bool(self._batch.read_output("truncated")[0])
+        done, truncated = bool(self._snap.terminated), bool(self._snap.truncated)
         self.historical_info.add(**self._row(position_index, real_position=self._real_position,
                                              valuation=self._portfolio_value))
         if not done:
             reward = (self.reward_function(self.historical_info) if self._host_reward
-                      else np.float64(self._batch.read_output("reward64")[0]))
+                      else np.float64(self._snap.reward))
             self.historical_info["reward", -1] = reward
         if done or truncated:
             self.calculate_metrics()

@@ -285,6 +285,22 @@ int gte_get_outputs(gte_env* env, gte_outputs* out);
  * it.  Call it again after later steps (the pointers stay the same). */
 int gte_get_state(gte_env* env, gte_state_view* out);
 
+/* Everything the reference's step()/reset() hand back for ONE env (environments.py:253-272:
+ * the History row and the return tuple), fetched with one device->host transfer. */
+typedef struct gte_env_snapshot {
+  int32_t idx, step, position_index, dataset_index;
+  int32_t start_idx, episode, needs_reset, terminated, truncated, reserved;
+  double asset, fiat, interest_asset, interest_fiat;   /* Portfolio, portfolio.py:1-6 */
+  double portfolio_valuation, real_position;           /* :241, :259 */
+  double reward;                                       /* f64, :265-267 */
+} gte_env_snapshot;
+
+/* State + returns + observation of env `env_index` after the last step/reset, into HOST
+ * memory: a small kernel packs them into pinned host memory on the env's stream, then the
+ * stream is synchronised once.  `obs` (W*F_obs floats) may be NULL.  This is what the N=1
+ * drop-in TradingEnv calls once per step instead of a dozen separate copies. */
+int gte_read_env(gte_env* env, int32_t env_index, gte_env_snapshot* out, float* obs);
+
 /* Use caller-owned device buffers for the outputs (e.g. torch tensors that are
  * then all-gathered over RCCL).  NULL members keep the library's buffer. */
 int gte_bind_outputs(gte_env* env, const gte_outputs* bufs);

@@ -272,3 +272,38 @@ def test_batched_history_and_custom_metrics_match_single_env(tmp_path):
     with pytest.raises(ValueError):
         BatchedTradingEnv(df, num_envs=2, output="numpy").add_metric("x", length)
     single.close(); batch.close()
+
+
+def test_read_env_snapshot_equals_separate_reads():
+    """gte_read_env (one transfer: state + returns + observation of one env) against the
+    field-by-field accessors, for several envs of a batch, after reset and after steps."""
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    rng = np.random.default_rng(5)
+    T, N = 300, 200
+    close = 100 * np.exp(np.cumsum(rng.normal(0, 2e-2, T)))
+    feat = rng.normal(0, 1, (T, 3)).astype(np.float32)
+    env = BatchedTradingEnv((feat, close), num_envs=N, positions=[-1, 0, 1], windows=6,
+                            trading_fees=1e-3, borrow_interest_rate=1e-4, max_episode_duration=15,
+                            output="numpy", seed=2)
+    with pytest.raises(Exception):
+        env.read_env(0)  # before reset
+    env.reset()
+    for k in range(20):
+        if k:
+            env.step(rng.integers(-1, 3, N).astype(np.int32))
+        obs_all = env.read_output("obs")
+        for e in (0, 63, 64, N - 1):
+            snap, obs = env.read_env(e)
+            for f in ("idx", "step", "position_index", "dataset_index", "start_idx", "episode",
+                      "needs_reset", "asset", "fiat", "interest_asset", "interest_fiat",
+                      "portfolio_valuation", "real_position"):
+                assert getattr(snap, f) == env.state(f)[e], (k, e, f)
+            assert snap.reward == env.read_output("reward64")[e]
+            assert snap.terminated == env.read_output("terminated")[e]
+            assert snap.truncated == env.read_output("truncated")[e]
+            np.testing.assert_array_equal(obs, obs_all[e])
+    snap, obs = env.read_env(3, with_obs=False)
+    assert obs is None and snap.idx == env.state("idx")[3]
+    with pytest.raises(Exception):
+        env.read_env(N)
+    env.close()
