@@ -90,6 +90,14 @@ class GteEnvSnapshot(C.Structure):
                                           "portfolio_valuation", "real_position", "reward")]
 
 
+# numpy view of an array of gte_env_snapshot (gte_read_envs)
+SNAPSHOT_DTYPE = [(n, "<i4") for n in ("idx", "step", "position_index", "dataset_index",
+                                       "start_idx", "episode", "needs_reset", "terminated",
+                                       "truncated", "reserved")] + \
+                 [(n, "<f8") for n in ("asset", "fiat", "interest_asset", "interest_fiat",
+                                       "portfolio_valuation", "real_position", "reward")]
+
+
 class GteRolloutBufs(C.Structure):
     """struct gte_rollout_bufs (include/gte.h): optional per-step result arrays."""
     _fields_ = [("obs", C.c_void_p), ("reward", C.c_void_p), ("reward64", C.c_void_p),
@@ -161,6 +169,7 @@ SYMBOLS = {
     "gte_get_state": (C.c_int, [C.c_void_p, _P(GteStateView)]),
     "gte_bind_outputs": (C.c_int, [C.c_void_p, _P(GteOutputs)]),
     "gte_read_env": (C.c_int, [C.c_void_p, C.c_int32, _P(GteEnvSnapshot), C.c_void_p]),
+    "gte_read_envs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "gte_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, _P(GteRolloutBufs)]),
     "gte_bind_returns": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gte_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

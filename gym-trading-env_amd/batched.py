@@ -201,6 +201,7 @@ class BatchedTradingEnv(_VectorEnvBase):
 
         self._state = _abi.GteStateView()
         self._epoch, self._state_epoch = 0, -1  # state snapshots are taken lazily
+        self._snap_epoch, self._snap, self._snap_obs = -1, None, None  # numpy mode, per step
         self._torch = None
         self._t = {}
         if output == "torch":
@@ -289,6 +290,8 @@ class BatchedTradingEnv(_VectorEnvBase):
     def state(self, name: str) -> np.ndarray:
         """Host copy of one per-env state array (struct gte_state_view member)."""
         dt = _NP[_abi.STATE_DTYPES[name]]
+        if self._snap_epoch == self._epoch:  # numpy mode: already fetched with the results
+            return np.ascontiguousarray(self._snap[name])
         if self._state_epoch != self._epoch:  # snapshot once per step/reset, not per field
             _abi.check(self._lib, self._lib.gte_get_state(self._h, C.byref(self._state)))
             self._state_epoch = self._epoch
@@ -422,9 +425,12 @@ class BatchedTradingEnv(_VectorEnvBase):
         if self.output == "torch":
             t = self._t
             return t["obs"], t["reward"], t["terminated"], t["truncated"]
-        return (self.read_output("obs"), self.read_output("reward64"),
-                self.read_output("terminated").astype(bool),
-                self.read_output("truncated").astype(bool))
+        # host arrays: state, returns and observations of the whole batch in ONE transfer
+        self._snap, self._snap_obs = self.read_envs()
+        self._snap_epoch = self._epoch
+        snap = self._snap
+        return (self._snap_obs, np.ascontiguousarray(snap["reward"]),
+                snap["terminated"].astype(bool), snap["truncated"].astype(bool))
 
     # -- the Env API -------------------------------------------------------------------
     def reset(self, seed=None, options=None, *, mask=None, inject_idx=None,
@@ -510,6 +516,18 @@ class BatchedTradingEnv(_VectorEnvBase):
                 raise IndexError("list index out of range")  # positions[position_index] (:234)
             _abi.check(self._lib, self._lib.gte_step(self._h, a.ctypes.data, 0))
         self._epoch += 1
+
+    def read_envs(self, first: int = 0, count=None, with_obs: bool = True):
+        """(snapshots, obs): a structured array [count] with the fields of struct
+        gte_env_snapshot (state, reward f64, terminated, truncated) and the observations
+        [count, *obs_shape] (or None) of envs first..first+count-1, fetched with one
+        device->host transfer (`gte_read_envs`)."""
+        count = self.num_envs - first if count is None else int(count)
+        snap = np.empty(count, dtype=_abi.SNAPSHOT_DTYPE)
+        obs = np.empty((count,) + self.obs_shape, np.float32) if with_obs else None
+        _abi.check(self._lib, self._lib.gte_read_envs(
+            self._h, int(first), count, snap.ctypes.data, obs.ctypes.data if with_obs else None))
+        return snap, obs
 
     def read_env(self, env_index: int = 0, with_obs: bool = True):
         """(GteEnvSnapshot, obs ndarray | None) of ONE env after the last step/reset: state,

@@ -47,8 +47,8 @@ hipError_t launch_log(const EnvRec* rec, const double* reward64, const uint8_t* 
                       const uint8_t* trunc, int n, int64_t row_base, const LogArrays& o,
                       hipStream_t stream);
 hipError_t launch_snapshot(const EnvRec* rec, const double* reward64, const uint8_t* term,
-                           const uint8_t* trunc, const float* obs, int64_t obs_elems, int e,
-                           void* dst, float* dst_obs, hipStream_t stream);
+                           const uint8_t* trunc, const float* obs, int64_t obs_elems, int first,
+                           int count, void* dst, float* dst_obs, hipStream_t stream);
 hipError_t launch_affinity_rebuild(const Params& p, int32_t* bins, int n_bins_per_ds,
                                    const int32_t* slot_of_rank, int32_t* perm_out,
                                    hipStream_t stream);
@@ -116,7 +116,8 @@ struct gte_env {
   gte::StateSoA soa = {};  // host-facing struct-of-arrays mirrors (gte_get_state)
   gte::LogArrays log = {}; // device trajectory log (cfg.log_steps rows per env)
   int64_t log_rows = 0;
-  void* h_snap = nullptr;  // pinned host memory for gte_read_env: snapshot + one observation
+  void* h_snap = nullptr;  // pinned host memory for gte_read_envs: snapshots, then observations
+  size_t h_snap_bytes = 0;
 };
 
 template <typename T>
@@ -739,21 +740,33 @@ int gte_bind_outputs(gte_env* E, const gte_outputs* b) {
 
 static_assert(sizeof(gte_env_snapshot) == 96, "gte_env_snapshot layout");
 
-int gte_read_env(gte_env* E, int32_t e, gte_env_snapshot* out, float* obs) {
+int gte_read_envs(gte_env* E, int32_t first, int32_t count, gte_env_snapshot* out, float* obs) {
   if (!E || !out) return fail(GTE_ERR_INVALID, "NULL argument");
-  if (!E->was_reset) return fail(GTE_ERR_STATE, "gte_read_env before gte_reset");
-  if (e < 0 || e >= E->p.N) return fail(GTE_ERR_INVALID, "env_index %d out of range", e);
+  if (!E->was_reset) return fail(GTE_ERR_STATE, "gte_read_envs before gte_reset");
+  if (first < 0 || count < 1 || (int64_t)first + count > E->p.N)
+    return fail(GTE_ERR_INVALID, "envs %d..%lld out of range", first, (long long)first + count - 1);
   HIPCHK(hipSetDevice(E->cfg.device));
-  const int64_t elems = (int64_t)E->p.W * E->p.Fobs;
-  if (!E->h_snap)  // pinned and mapped: the kernel writes host memory directly
-    HIPCHK(hipHostMalloc(&E->h_snap, 128 + sizeof(float) * (size_t)elems, hipHostMallocMapped));
-  float* h_obs = (float*)((char*)E->h_snap + 128);
+  const size_t elems = (size_t)E->p.W * (size_t)E->p.Fobs;
+  const size_t head = sizeof(gte_env_snapshot) * (size_t)count;  // 96 B each: 16-byte aligned
+  const size_t need = head + (obs ? sizeof(float) * elems * (size_t)count : 0);
+  if (need > E->h_snap_bytes) {  // pinned and mapped: the kernel writes host memory directly
+    if (E->h_snap) HIPCHK(hipHostFree(E->h_snap));
+    E->h_snap = nullptr; E->h_snap_bytes = 0;
+    HIPCHK(hipHostMalloc(&E->h_snap, need, hipHostMallocMapped));
+    E->h_snap_bytes = need;
+  }
+  float* h_obs = (float*)((char*)E->h_snap + head);
   HIPCHK(gte::launch_snapshot(E->p.rec, E->p.reward64, E->p.terminated, E->p.truncated, E->p.obs,
-                              elems, e, E->h_snap, obs ? h_obs : nullptr, E->stream));
+                              (int64_t)elems, first, count, E->h_snap, obs ? h_obs : nullptr,
+                              E->stream));
   HIPCHK(hipStreamSynchronize(E->stream));
-  memcpy(out, E->h_snap, sizeof(gte_env_snapshot));
-  if (obs) memcpy(obs, h_obs, sizeof(float) * (size_t)elems);
+  memcpy(out, E->h_snap, head);
+  if (obs) memcpy(obs, h_obs, sizeof(float) * elems * (size_t)count);
   return GTE_OK;
+}
+
+int gte_read_env(gte_env* E, int32_t e, gte_env_snapshot* out, float* obs) {
+  return gte_read_envs(E, e, 1, out, obs);
 }
 
 int gte_bind_returns(gte_env* E, float* reward, uint8_t* terminated, uint8_t* truncated) {

@@ -34,8 +34,8 @@ hipError_t launch_log(const EnvRec* rec, const double* reward64, const uint8_t* 
 }
 
 // ---------------------------------------------------------------------------
-// One env's state, returns and observation, packed into (pinned, device-visible) host
-// memory: struct gte_env_snapshot first, the observation after it.
+// State, returns and observation of a range of envs, packed into (pinned, device-visible)
+// host memory: `count` gte_env_snapshot structs, then `count` observations.
 struct SnapshotPacked {
   int32_t idx, step, pos, dsi, start, episode, needs_reset, terminated, truncated, reserved;
   double asset, fiat, ia, ifi, pv, realpos, reward;
@@ -43,7 +43,8 @@ struct SnapshotPacked {
 
 __global__ void gte_snapshot_kernel(const EnvRec* rec, const double* reward64, const uint8_t* term,
                                     const uint8_t* trunc, const float* obs, int64_t obs_elems,
-                                    int e, SnapshotPacked* dst, float* dst_obs) {
+                                    int first, SnapshotPacked* dst, float* dst_obs) {
+  const int e = first + blockIdx.x;  // one workgroup per env
   if (threadIdx.x == 0) {
     const EnvRec r = rec[e];
     SnapshotPacked s;
@@ -52,18 +53,18 @@ __global__ void gte_snapshot_kernel(const EnvRec* rec, const double* reward64, c
     s.terminated = term[e]; s.truncated = trunc[e]; s.reserved = 0;
     s.asset = r.asset; s.fiat = r.fiat; s.ia = r.ia; s.ifi = r.ifi; s.pv = r.pv;
     s.realpos = r.realpos; s.reward = reward64[e];
-    *dst = s;
+    dst[blockIdx.x] = s;
   }
   if (dst_obs)
     for (int64_t i = threadIdx.x; i < obs_elems; i += blockDim.x)
-      dst_obs[i] = obs[(int64_t)e * obs_elems + i];
+      dst_obs[(int64_t)blockIdx.x * obs_elems + i] = obs[(int64_t)e * obs_elems + i];
 }
 
 hipError_t launch_snapshot(const EnvRec* rec, const double* reward64, const uint8_t* term,
-                           const uint8_t* trunc, const float* obs, int64_t obs_elems, int e,
-                           void* dst, float* dst_obs, hipStream_t stream) {
-  hipLaunchKernelGGL(gte_snapshot_kernel, dim3(1), dim3(256), 0, stream, rec, reward64, term, trunc,
-                     obs, obs_elems, e, (SnapshotPacked*)dst, dst_obs);
+                           const uint8_t* trunc, const float* obs, int64_t obs_elems, int first,
+                           int count, void* dst, float* dst_obs, hipStream_t stream) {
+  hipLaunchKernelGGL(gte_snapshot_kernel, dim3(count), dim3(256), 0, stream, rec, reward64, term,
+                     trunc, obs, obs_elems, first, (SnapshotPacked*)dst, dst_obs);
   return hipGetLastError();
 }
 

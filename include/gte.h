@@ -295,10 +295,13 @@ typedef struct gte_env_snapshot {
   double reward;                                       /* f64, :265-267 */
 } gte_env_snapshot;
 
-/* State + returns + observation of env `env_index` after the last step/reset, into HOST
- * memory: a small kernel packs them into pinned host memory on the env's stream, then the
- * stream is synchronised once.  `obs` (W*F_obs floats) may be NULL.  This is what the N=1
- * drop-in TradingEnv calls once per step instead of a dozen separate copies. */
+/* State + returns + observations of envs first .. first+count-1 after the last step/reset,
+ * into HOST memory: a small kernel (one workgroup per env) packs them into pinned host memory
+ * on the env's stream, then the stream is synchronised once.  `out` receives `count` snapshots,
+ * `obs` (count * W*F_obs floats) may be NULL.  This is what the host-array ("numpy") mode of
+ * the Python classes calls once per step instead of one copy per field. */
+int gte_read_envs(gte_env* env, int32_t first, int32_t count, gte_env_snapshot* out, float* obs);
+/* gte_read_envs for one env (the N=1 drop-in TradingEnv's per-step call). */
 int gte_read_env(gte_env* env, int32_t env_index, gte_env_snapshot* out, float* obs);
 
 /* Use caller-owned device buffers for the outputs (e.g. torch tensors that are

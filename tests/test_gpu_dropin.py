@@ -290,7 +290,16 @@ def test_read_env_snapshot_equals_separate_reads():
     env.reset()
     for k in range(20):
         if k:
-            env.step(rng.integers(-1, 3, N).astype(np.int32))
+            obs_k, reward_k, term_k, trunc_k, _ = env.step(rng.integers(-1, 3, N).astype(np.int32))
+            cached_pv = env.state("portfolio_valuation")  # numpy mode: came with the results
+            env._snap_epoch = -1  # from here on state() goes through gte_get_state again
+            np.testing.assert_array_equal(cached_pv, env.state("portfolio_valuation"))
+            np.testing.assert_array_equal(obs_k, env.read_output("obs"))
+            np.testing.assert_array_equal(reward_k, env.read_output("reward64"))
+            np.testing.assert_array_equal(term_k, env.read_output("terminated").astype(bool))
+            np.testing.assert_array_equal(trunc_k, env.read_output("truncated").astype(bool))
+        else:
+            env._snap_epoch = -1
         obs_all = env.read_output("obs")
         for e in (0, 63, 64, N - 1):
             snap, obs = env.read_env(e)
@@ -304,6 +313,9 @@ def test_read_env_snapshot_equals_separate_reads():
             np.testing.assert_array_equal(obs, obs_all[e])
     snap, obs = env.read_env(3, with_obs=False)
     assert obs is None and snap.idx == env.state("idx")[3]
+    some, some_obs = env.read_envs(60, 10)
+    np.testing.assert_array_equal(some["idx"], env.state("idx")[60:70])
+    np.testing.assert_array_equal(some_obs, env.read_output("obs")[60:70])
     with pytest.raises(Exception):
         env.read_env(N)
     env.close()
