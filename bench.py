@@ -274,7 +274,7 @@ def main():
                            + (",obs)" if args.gather_obs else ")")
                            + (f" in {block}-step blocks overlapping the following steps"
                               if depth > 1 else ", synchronous per step")),
-                       "launch": info, "store_policy": int(env.cfg.nontemporal_obs),
+                       "launch": info,
                        "episodes_finished": episodes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

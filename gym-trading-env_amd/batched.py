@@ -140,7 +140,7 @@ class BatchedTradingEnv(_VectorEnvBase):
                  name="Stock", render_mode="logs", *, autoreset="next_step",
                  episodes_between_dataset_switch=1, dyn_persist=False, seed=0,
                  env_id_base=0, device=0, output="torch", envs_per_wave=0,
-                 nontemporal_obs=2, kernel_variant=0, library_path=None, debug_flags=0,
+                 nontemporal_obs=3, kernel_variant=0, library_path=None, debug_flags=0,
                  affinity_period=0, final_obs=False, log_steps=0, return_slots=1):
         assert render_mode is None or render_mode in self.metadata["render_modes"]
         if output not in ("torch", "numpy"):
@@ -596,6 +596,7 @@ class BatchedTradingEnv(_VectorEnvBase):
         d["dyn_columns"] = ("global", "lds-raw-rings", "lds-resolved")[(flags >> 1) & 3]
         d["structure"] = ("overlapped (waves 1-3 copy predicted windows during phase A)"
                           if flags & 8 else "classic (phase A, barrier, gather)")
+        d["obs_stores"] = ("plain", "non-temporal", "sc1", "?")[(flags >> 4) & 3]
         return d
 
     def timer_start(self):

@@ -83,7 +83,7 @@ def make_config(*, n_envs: int, n_static: int, n_datasets: int = 1,
                 episodes_between_dataset_switch: int = 1,
                 dyn_persist: bool = False, seed: int = 0, env_id_base: int = 0,
                 device: int = 0, envs_per_wave: int = 0,
-                nontemporal_obs: int = 2, kernel_variant: int = 0,
+                nontemporal_obs: int = 3, kernel_variant: int = 0,
                 debug_flags: int = 0, affinity_period: int = 0,
                 final_obs: bool = False, log_steps: int = 0) -> _abi.GteConfig:
     positions = list(positions)
@@ -137,7 +137,7 @@ def make_config(*, n_envs: int, n_static: int, n_datasets: int = 1,
     cfg.seed = int(seed) & (2**64 - 1)
     cfg.env_id_base = int(env_id_base)
     cfg.envs_per_wave = int(envs_per_wave)
-    cfg.nontemporal_obs = int(nontemporal_obs)  # 0 plain, 1 nt, 2 sc1
+    cfg.nontemporal_obs = int(nontemporal_obs)  # 0 plain, 1 nt, 2 sc1, 3 automatic
     cfg.kernel_variant = int(kernel_variant)
     cfg.debug_flags = int(debug_flags)
     cfg.affinity_period = int(affinity_period)

@@ -24,6 +24,9 @@ hipError_t launch_reset(const Params& p, int vec, int nt, bool coop, int stage, 
                         int threads, hipStream_t stream);
 size_t lds_bytes(const Params& p, int stage);
 hipError_t launch_step_hot(const Params& p, int blocks, int threads, size_t smem, hipStream_t stream);
+hipError_t launch_step_hot_nt(const Params& p, int blocks, int threads, size_t smem, hipStream_t stream);
+int hot_blocks_per_cu(size_t smem);
+int hot_blocks_per_cu_nt(size_t smem);
 size_t lds_bytes_overlap(const Params& p);
 struct RolloutArgs {  // mirrors gte_rollout.hip
   const int32_t* actions; int32_t K; float* obs; float* reward; double* reward64;
@@ -116,6 +119,7 @@ struct gte_env {
   gte::StateSoA soa = {};  // host-facing struct-of-arrays mirrors (gte_get_state)
   gte::LogArrays log = {}; // device trajectory log (cfg.log_steps rows per env)
   int64_t log_rows = 0;
+  bool store_auto = false; // the observation store policy was chosen here (cfg said 3)
   void* h_snap = nullptr;  // pinned host memory for gte_read_envs: snapshots, then observations
   size_t h_snap_bytes = 0;
 };
@@ -171,14 +175,13 @@ static int validate(const gte_config* c) {
     return fail(GTE_ERR_INVALID, "autoreset %d unknown", c->autoreset);
   if (c->episodes_between_dataset_switch < 1)
     return fail(GTE_ERR_INVALID, "episodes_between_dataset_switch must be >= 1");
-  if (c->nontemporal_obs < 0 || c->nontemporal_obs > 2)
-    return fail(GTE_ERR_INVALID, "nontemporal_obs must be 0 (plain), 1 (nt) or 2 (sc1)");
+  if (c->nontemporal_obs < 0 || c->nontemporal_obs > 3)
+    return fail(GTE_ERR_INVALID, "nontemporal_obs must be 0 (plain), 1 (nt), 2 (sc1) or 3 (automatic)");
   if (c->log_steps < 0) return fail(GTE_ERR_INVALID, "log_steps must be >= 0");
   if (c->final_obs && c->autoreset != GTE_AUTORESET_SAME_STEP)
     return fail(GTE_ERR_INVALID, "final_obs needs autoreset = same-step");
-  if (c->envs_per_wave != 0 &&
-      (c->envs_per_wave < 1 || c->envs_per_wave > 64 || (c->envs_per_wave & (c->envs_per_wave - 1))))
-    return fail(GTE_ERR_INVALID, "envs_per_wave must be 0 or a power of two <= 64");
+  if (c->envs_per_wave < 0 || c->envs_per_wave > 64)
+    return fail(GTE_ERR_INVALID, "envs_per_wave must be 0 (automatic) or 1..64");
   return GTE_OK;
 }
 
@@ -300,6 +303,14 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   E->h_ds.assign((size_t)p.D, DatasetDesc{nullptr, nullptr, nullptr, nullptr, 0});
   for (auto& v : E->ds_allocs) v.assign((size_t)p.D, nullptr);
 
+  // observation store policy (gte_kernels.hip, store_out): while the observation buffer fits
+  // the 256 MB Infinity Cache next to the feature table, sc1 stores keep it there (65 536 envs,
+  // 168 MB: 42.5 us vs 45.8 us with nt); beyond that the stores are a pure stream and
+  // non-temporal ones win (81 920 envs, 210 MB: 48 us vs 58 us; 262 144 envs: 162 us vs 261 us)
+  E->store_auto = E->cfg.nontemporal_obs == 3;
+  if (E->store_auto)
+    E->cfg.nontemporal_obs = ((size_t)N * p.W * p.Fobs * sizeof(float) > ((size_t)190 << 20)) ? 1 : 2;
+
   // launch geometry: EPW environments per wavefront, 4 wavefronts per workgroup
   E->vec = (p.Fobs % 4 == 0) ? 4 : 1;
   const int64_t vpe = (int64_t)p.W * p.Fobs / E->vec;  // vectors per env
@@ -314,6 +325,34 @@ int gte_create(const gte_config* cfg, gte_env** out) {
     // (small windows are latency-bound: 16 envs/wave with cooperative phase A measured
     // 5.4 us vs 7.5 us at 64 envs/wave on config 2, profiles/r01_tune_c2.log)
     while (epw < 64 && (int64_t)epw * vpe < 64) epw <<= 1;
+    // Windowed shapes on the hot kernel: size the workgroups so that ALL of them are resident
+    // at once (or a whole number of such rounds).  A CU holds 5 workgroups of the hot kernel,
+    // 1280 in all; 65 536 envs as 1024 workgroups of 64 leave a fifth of the slots empty
+    // (42.9 us), as 1261 workgroups of 52 (13 per wave) they fill them (39.8 us), and as 1366
+    // workgroups of 48 the last 86 run alone afterwards (57.5 us) — profiles/r01_tune_epw.log.
+    // Cost model: rounds x (fixed part of a workgroup + its copy work).
+    const bool hot_shape = E->vec == 4 && vpe >= 64 && p.nd > 0 && !p.persist && !cfg->final_obs &&
+                           (E->cfg.nontemporal_obs == 1 || E->cfg.nontemporal_obs == 2) &&
+                           !(cfg->kernel_variant & (1 | 2 | 4));
+    if (hot_shape) {
+      Params q = p;
+      q.epw = 16;
+      const size_t smem = gte::lds_bytes(q, 1);
+      const int per_cu = E->cfg.nontemporal_obs == 1 ? gte::hot_blocks_per_cu_nt(smem)
+                                                      : gte::hot_blocks_per_cu(smem);
+      hipDeviceProp_t prop;
+      if (per_cu > 0 && hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
+        const int64_t slots = (int64_t)per_cu * prop.multiProcessorCount;
+        double best = 0.0;
+        for (int e = 16; e >= 1; --e) {
+          if ((int64_t)e * vpe < 64) break;
+          const int64_t wgs = ((int64_t)p.N + 4 * e - 1) / (4 * e);
+          const int64_t rounds = (wgs + slots - 1) / slots;
+          const double cost = (double)rounds * (10.0 + 2.0 * e * (double)vpe / 160.0);
+          if (best == 0.0 || cost < best) { best = cost; epw = e; }
+        }
+      }
+    }
   }
   while (epw > 1 && (int64_t)epw * vpe > (1 << 20)) epw >>= 1;  // keeps the index math in range
   // the LDS-staged dynamic columns must fit comfortably: shrink the workgroup's envs
@@ -558,6 +597,9 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
   else if (E->vec == 4 && E->cfg.nontemporal_obs == 2 && E->coop && E->stage == 1 &&
            !(E->cfg.kernel_variant & 64))
     HIPCHK(gte::launch_step_hot(p, E->blocks, E->threads, gte::lds_bytes(p, E->stage), E->stream));
+  else if (E->vec == 4 && E->cfg.nontemporal_obs == 1 && E->coop && E->stage == 1 &&
+           !(E->cfg.kernel_variant & 64))
+    HIPCHK(gte::launch_step_hot_nt(p, E->blocks, E->threads, gte::lds_bytes(p, E->stage), E->stream));
   else
     HIPCHK(gte::launch_step(p, E->vec, E->cfg.nontemporal_obs, E->coop, E->stage, E->blocks,
                             E->threads, E->stream));
@@ -584,6 +626,9 @@ int gte_rollout(gte_env* E, const int32_t* actions, int32_t n_steps, const gte_r
                        !(E->cfg.kernel_variant & 256);
   const bool fused = E->vec == 4 && E->coop && E->stage == 1 && !E->overlap && !E->cfg.final_obs &&
                      E->cfg.log_steps == 0 && !(E->cfg.kernel_variant & 128) && !big_obs;
+  // per-step observation rows are written once and not read back by the kernels: a stream
+  const int store_keep = E->cfg.nontemporal_obs;
+  if (b->obs && E->store_auto) E->cfg.nontemporal_obs = 1;
   if (!fused) {
     // same results, one launch per step: point the step kernel at row k of every buffer
     const Params keep = E->p;
@@ -605,7 +650,7 @@ int gte_rollout(gte_env* E, const int32_t* actions, int32_t n_steps, const gte_r
     }
     E->p.obs = keep.obs; E->p.reward = keep.reward; E->p.reward64 = keep.reward64;
     E->p.terminated = keep.terminated; E->p.truncated = keep.truncated;
-    if (rc != GTE_OK) return rc;
+    if (rc != GTE_OK) { E->cfg.nontemporal_obs = store_keep; return rc; }
   } else {
     if (E->affinity_period > 0) {
       E->steps_since_rebuild += n_steps;
@@ -621,8 +666,14 @@ int gte_rollout(gte_env* E, const int32_t* actions, int32_t n_steps, const gte_r
     p.term_count_next = E->term_base + (E->term_slot ^ 1);
     gte::RolloutArgs r = {actions, n_steps, b->obs, b->reward, b->reward64, b->terminated,
                           b->truncated, b->valuation};
-    HIPCHK(gte::launch_rollout(p, r, E->cfg.nontemporal_obs, E->blocks, E->threads, E->stream));
+    const hipError_t le = gte::launch_rollout(p, r, E->cfg.nontemporal_obs, E->blocks, E->threads,
+                                              E->stream);
+    if (le != hipSuccess) {
+      E->cfg.nontemporal_obs = store_keep;
+      return fail(GTE_ERR_HIP, "rollout launch: %s", hipGetErrorString(le));
+    }
   }
+  E->cfg.nontemporal_obs = store_keep;
   // the env's own return buffers describe the last step
   const size_t last = (size_t)(n_steps - 1) * N;
   if (b->reward) HIPCHK(hipMemcpyAsync(E->p.reward, b->reward + last, 4 * N, hipMemcpyDeviceToDevice, E->stream));
@@ -852,7 +903,9 @@ int gte_get_launch_info(gte_env* E, int32_t* envs_per_wave, int32_t* threads_per
   if (envs_per_wave) *envs_per_wave = E->p.epw;
   if (threads_per_block) *threads_per_block = E->threads;
   if (n_blocks) *n_blocks = E->blocks;
-  if (vector_bytes) *vector_bytes = E->vec * 4 + 1000 * ((E->coop ? 1 : 0) + 2 * E->stage + (E->overlap ? 8 : 0));
+  if (vector_bytes)
+    *vector_bytes = E->vec * 4 + 1000 * ((E->coop ? 1 : 0) + 2 * E->stage + (E->overlap ? 8 : 0) +
+                                         16 * E->cfg.nontemporal_obs);
   return GTE_OK;
 }
 

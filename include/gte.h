@@ -107,10 +107,13 @@ typedef struct gte_config {
   int64_t  env_id_base;     /* global id of env 0 of this shard (RNG streams
                                are keyed by global env id, so a sharded run
                                equals the unsharded one)                       */
-  int32_t envs_per_wave;    /* 0 = choose automatically                        */
+  int32_t envs_per_wave;    /* 0 = choose automatically (so that all workgroups are
+                               resident at once where possible), else 1..64       */
   int32_t nontemporal_obs;  /* observation store policy: 0 plain, 1 non-temporal, 2 sc1
                                (1 and 2 keep the feature table in L2; see
-                               store_out in csrc/gte_kernels.hip)                 */
+                               store_out in csrc/gte_kernels.hip), 3 = automatic:
+                               sc1 while the observation buffer fits the Infinity
+                               Cache (<= 190 MB), non-temporal beyond             */
   int32_t kernel_variant;   /* 0 = auto.  Bits for A/B timing of the kernel structure:
                                1 = every wave runs phase A for its own envs (no
                                cooperative phase A), 2 = no LDS staging of the
@@ -335,7 +338,10 @@ int gte_read_obs(gte_env* env, int32_t first_env, int32_t n, float* host_dst);
 int gte_copy_to_host(gte_env* env, const void* device_src, void* host_dst,
                      uint64_t bytes);
 
-/* kernel geometry actually used (for DESIGN.md / bench output) */
+/* kernel geometry actually used (for DESIGN.md / bench output).  *vector_bytes = bytes per
+ * copy vector + 1000 * flags: bit 0 cooperative phase A, bits 1-2 staging of the dynamic
+ * columns (0 none, 1 raw rings in LDS, 2 resolved in LDS), bit 3 overlapped kernel, bits 4-5
+ * the observation store policy in use (0 plain, 1 nt, 2 sc1; never 3). */
 int gte_get_launch_info(gte_env* env, int32_t* envs_per_wave,
                         int32_t* threads_per_block, int32_t* n_blocks,
                         int32_t* vector_bytes);

@@ -61,7 +61,8 @@ def test_hip_matches_reference_trace(name):
 
 
 @pytest.mark.parametrize("name,epw", [("c3_window20", 1), ("c3_window20", 4), ("c2_nowindow", 64),
-                                      ("drawdown_done", 2), ("multidataset_k1", 8)])
+                                      ("drawdown_done", 2), ("multidataset_k1", 8),
+                                      ("c3_window20", 13), ("limit_orders", 7), ("c2_nowindow", 5)])
 def test_hip_trace_tiled_across_waves(name, epw):
     """Same traces, envs tiled 67x so that they span many wavefronts / workgroups and a
     ragged last wave, for several envs-per-wave geometries."""
