@@ -597,6 +597,7 @@ class BatchedTradingEnv(_VectorEnvBase):
         d["structure"] = ("overlapped (waves 1-3 copy predicted windows during phase A)"
                           if flags & 8 else "classic (phase A, barrier, gather)")
         d["obs_stores"] = ("plain", "non-temporal", "sc1", "?")[(flags >> 4) & 3]
+        d["resident_workgroups_per_cu"] = (flags >> 6) & 15
         return d
 
     def timer_start(self):

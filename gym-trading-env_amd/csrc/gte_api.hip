@@ -119,6 +119,7 @@ struct gte_env {
   gte::StateSoA soa = {};  // host-facing struct-of-arrays mirrors (gte_get_state)
   gte::LogArrays log = {}; // device trajectory log (cfg.log_steps rows per env)
   int64_t log_rows = 0;
+  int hot_per_cu = 0;      // resident workgroups per CU the geometry was sized for (0 = n/a)
   bool store_auto = false; // the observation store policy was chosen here (cfg said 3)
   void* h_snap = nullptr;  // pinned host memory for gte_read_envs: snapshots, then observations
   size_t h_snap_bytes = 0;
@@ -335,21 +336,22 @@ int gte_create(const gte_config* cfg, gte_env** out) {
                            (E->cfg.nontemporal_obs == 1 || E->cfg.nontemporal_obs == 2) &&
                            !(cfg->kernel_variant & (1 | 2 | 4));
     if (hot_shape) {
-      Params q = p;
-      q.epw = 16;
-      const size_t smem = gte::lds_bytes(q, 1);
-      const int per_cu = E->cfg.nontemporal_obs == 1 ? gte::hot_blocks_per_cu_nt(smem)
-                                                      : gte::hot_blocks_per_cu(smem);
       hipDeviceProp_t prop;
-      if (per_cu > 0 && hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
-        const int64_t slots = (int64_t)per_cu * prop.multiProcessorCount;
+      if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
         double best = 0.0;
         for (int e = 16; e >= 1; --e) {
           if ((int64_t)e * vpe < 64) break;
+          Params q = p;
+          q.epw = e;  // registers AND the workgroup's LDS (which shrinks with e) bound residency
+          const size_t smem = gte::lds_bytes(q, 1);
+          const int per_cu = E->cfg.nontemporal_obs == 1 ? gte::hot_blocks_per_cu_nt(smem)
+                                                          : gte::hot_blocks_per_cu(smem);
+          if (per_cu <= 0) break;
+          const int64_t slots = (int64_t)per_cu * prop.multiProcessorCount;
           const int64_t wgs = ((int64_t)p.N + 4 * e - 1) / (4 * e);
           const int64_t rounds = (wgs + slots - 1) / slots;
           const double cost = (double)rounds * (10.0 + 2.0 * e * (double)vpe / 160.0);
-          if (best == 0.0 || cost < best) { best = cost; epw = e; }
+          if (best == 0.0 || cost < best) { best = cost; epw = e; E->hot_per_cu = per_cu; }
         }
       }
     }
@@ -905,7 +907,7 @@ int gte_get_launch_info(gte_env* E, int32_t* envs_per_wave, int32_t* threads_per
   if (n_blocks) *n_blocks = E->blocks;
   if (vector_bytes)
     *vector_bytes = E->vec * 4 + 1000 * ((E->coop ? 1 : 0) + 2 * E->stage + (E->overlap ? 8 : 0) +
-                                         16 * E->cfg.nontemporal_obs);
+                                         16 * E->cfg.nontemporal_obs + 64 * (E->hot_per_cu & 15));
   return GTE_OK;
 }
 

@@ -341,7 +341,8 @@ int gte_copy_to_host(gte_env* env, const void* device_src, void* host_dst,
 /* kernel geometry actually used (for DESIGN.md / bench output).  *vector_bytes = bytes per
  * copy vector + 1000 * flags: bit 0 cooperative phase A, bits 1-2 staging of the dynamic
  * columns (0 none, 1 raw rings in LDS, 2 resolved in LDS), bit 3 overlapped kernel, bits 4-5
- * the observation store policy in use (0 plain, 1 nt, 2 sc1; never 3). */
+ * the observation store policy in use (0 plain, 1 nt, 2 sc1; never 3), bits 6-9 the resident
+ * workgroups per CU the automatic geometry was sized for (0 = not applicable). */
 int gte_get_launch_info(gte_env* env, int32_t* envs_per_wave,
                         int32_t* threads_per_block, int32_t* n_blocks,
                         int32_t* vector_bytes);

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--region-affine", type=int, default=0,
                     help="K>0: inject start rows so that workgroup b (64 envs) only reads table "
                          "region b %% K (potential of an XCD/L2-affine env order; K=8 XCDs)")
+    ap.add_argument("--lib", default=None, help="alternative libgte.so to load (A/B of builds)")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     import torch
@@ -44,6 +45,7 @@ def main():
                                     kernel_variant=int(kv), envs_per_wave=int(epw),
                                     nontemporal_obs=int(nt),
                                     debug_flags=int(dbg[0]) if dbg else 0, affinity_period=aff,
+                                    library_path=a.lib,
                                     **bench.env_kwargs(wl))
         if a.region_affine:
             K = a.region_affine
