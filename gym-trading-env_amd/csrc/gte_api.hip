@@ -34,6 +34,7 @@ struct RolloutArgs {  // mirrors gte_rollout.hip
 };
 hipError_t launch_rollout(const Params& p, const RolloutArgs& r, int nt, int blocks, int threads,
                           hipStream_t stream);
+int rollout_blocks_per_cu(const Params& p, int nt);
 hipError_t launch_step_overlap(const Params& p, int vec, int nt, hipStream_t stream);
 struct StateSoA {
   int32_t *idx, *step, *pos, *dsi, *start, *episode, *needs_reset;
@@ -119,6 +120,7 @@ struct gte_env {
   gte::StateSoA soa = {};  // host-facing struct-of-arrays mirrors (gte_get_state)
   gte::LogArrays log = {}; // device trajectory log (cfg.log_steps rows per env)
   int64_t log_rows = 0;
+  int rollout_epw = 0;     // envs per wavefront of the fused rollout kernel (0 = not chosen yet)
   int hot_per_cu = 0;      // resident workgroups per CU the geometry was sized for (0 = n/a)
   bool store_auto = false; // the observation store policy was chosen here (cfg said 3)
   void* h_snap = nullptr;  // pinned host memory for gte_read_envs: snapshots, then observations
@@ -609,6 +611,8 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
   return GTE_OK;
 }
 
+static bool cfg_is_auto_epw(const gte_env* E) { return E->cfg.envs_per_wave == 0; }
+
 int gte_rollout(gte_env* E, const int32_t* actions, int32_t n_steps, const gte_rollout_bufs* b) {
   if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
   if (!E->was_reset) return fail(GTE_ERR_STATE, "gte_rollout before gte_reset");
@@ -620,14 +624,9 @@ int gte_rollout(gte_env* E, const int32_t* actions, int32_t n_steps, const gte_r
   const size_t V = (size_t)E->p.W * (size_t)E->p.Fobs;
   if (b->obs && ((uintptr_t)b->obs & 15)) return fail(GTE_ERR_INVALID, "obs must be 16-byte aligned");
   HIPCHK(hipSetDevice(E->cfg.device));
-  // Per-step observations of a big batch are bound by HBM writes to fresh rows either way, and
-  // there K launches of the step kernel measure faster than the fused loop (config 3: 52 us vs
-  // 56 us per step; config 2: 5.8 us vs 3.9 us, the other way round), so the fused kernel takes
-  // every case except that one.  kernel_variant 128 = never fused, 256 = fused whenever it applies.
-  const bool big_obs = b->obs && N * V * sizeof(float) >= ((size_t)64 << 20) &&
-                       !(E->cfg.kernel_variant & 256);
+  // kernel_variant 128 = never fused (A/B and tests of the per-launch path)
   const bool fused = E->vec == 4 && E->coop && E->stage == 1 && !E->overlap && !E->cfg.final_obs &&
-                     E->cfg.log_steps == 0 && !(E->cfg.kernel_variant & 128) && !big_obs;
+                     E->cfg.log_steps == 0 && !(E->cfg.kernel_variant & 128);
   // per-step observation rows are written once and not read back by the kernels: a stream
   const int store_keep = E->cfg.nontemporal_obs;
   if (b->obs && E->store_auto) E->cfg.nontemporal_obs = 1;
@@ -663,12 +662,34 @@ int gte_rollout(gte_env* E, const int32_t* actions, int32_t n_steps, const gte_r
       }
     }
     Params p = E->p;
+    if (E->rollout_epw == 0) {
+      // The rollout kernel is a long-running loop: a workgroup that is not resident from the
+      // start runs all K steps after the others have finished.  It needs more registers than
+      // the step kernel (4 workgroups per CU instead of 5), so it gets its own workgroup size,
+      // the smallest that keeps every workgroup resident (the processing order `perm` does not
+      // depend on the workgroup size).
+      E->rollout_epw = p.epw;
+      hipDeviceProp_t prop;
+      if (cfg_is_auto_epw(E) && hipGetDeviceProperties(&prop, E->cfg.device) == hipSuccess) {
+        for (int e = 1; e <= 16; ++e) {
+          Params q = p;
+          q.epw = e;
+          if ((int64_t)e * p.W * p.Fobs / 4 < 64) continue;
+          const int per_cu = gte::rollout_blocks_per_cu(q, E->cfg.nontemporal_obs);
+          const int64_t wgs = ((int64_t)p.N + 4 * e - 1) / (4 * e);
+          if (per_cu > 0 && wgs <= (int64_t)per_cu * prop.multiProcessorCount) { E->rollout_epw = e; break; }
+          if (e == 16) E->rollout_epw = 16;  // more envs than one round holds: biggest workgroups
+        }
+      }
+    }
+    p.epw = E->rollout_epw;
+    const int r_blocks = (int)((((int64_t)p.N + p.epw - 1) / p.epw + 3) / 4);
     E->term_slot ^= 1;
     p.term_count = E->term_base + E->term_slot;
     p.term_count_next = E->term_base + (E->term_slot ^ 1);
     gte::RolloutArgs r = {actions, n_steps, b->obs, b->reward, b->reward64, b->terminated,
                           b->truncated, b->valuation};
-    const hipError_t le = gte::launch_rollout(p, r, E->cfg.nontemporal_obs, E->blocks, E->threads,
+    const hipError_t le = gte::launch_rollout(p, r, E->cfg.nontemporal_obs, r_blocks, E->threads,
                                               E->stream);
     if (le != hipSuccess) {
       E->cfg.nontemporal_obs = store_keep;

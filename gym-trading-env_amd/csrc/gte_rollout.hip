@@ -168,6 +168,17 @@ __global__ __launch_bounds__(256) void gte_rollout_kernel(const Params p0, const
   }
 }
 
+// Workgroups of the rollout kernel one CU holds at once with p.epw envs per wavefront.
+int rollout_blocks_per_cu(const Params& p, int nt) {
+  int n = 0;
+  const size_t smem = rollout_lds_bytes(p);
+  hipError_t e;
+  if (nt == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gte_rollout_kernel<2>, 256, smem);
+  else if (nt == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gte_rollout_kernel<1>, 256, smem);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gte_rollout_kernel<0>, 256, smem);
+  return e == hipSuccess ? n : 0;
+}
+
 hipError_t launch_rollout(const Params& p, const RolloutArgs& r, int nt, int blocks, int threads,
                           hipStream_t stream) {
   const size_t smem = rollout_lds_bytes(p);

@@ -123,9 +123,7 @@ typedef struct gte_config {
                                64 = launch the shared-TU instantiation of the hot
                                kernel instead of the isolated one (gte_hot.hip),
                                128 = gte_rollout runs as one launch per step even
-                               where the fused kernel applies, 256 = gte_rollout
-                               uses the fused kernel also for per-step observations
-                               of big batches (where it measures slower)           */
+                               where the fused kernel applies                      */
   int32_t debug_flags;      /* timing ablations only (results become wrong):
                                1 = skip the observation gather, 2 = skip the
                                dynamic-column patch, 8 = skip the window loads
@@ -275,9 +273,9 @@ typedef struct gte_rollout_bufs {
  * the results are exactly those of n_steps gte_step calls; afterwards the env's own reward /
  * flag buffers and terminal list describe the last step, and its obs buffer holds the last
  * observation unless bufs->obs was given (then that is row n_steps-1 of bufs->obs).  Shapes the
- * fused kernel does not cover (dyn_persist, final_obs, log_steps, scalar-vector layouts), and
- * per-step observations of >= 64 MB per step (HBM-write bound either way, measured faster as
- * separate launches), run as n_steps launches of the step kernel with the same results. */
+ * fused kernel does not cover (dyn_persist, final_obs, log_steps, scalar-vector layouts) run as
+ * n_steps launches of the step kernel with the same results.  Per-step observation rows are
+ * written with non-temporal stores under the automatic store policy (they are a stream). */
 int gte_rollout(gte_env* env, const int32_t* actions, int32_t n_steps, const gte_rollout_bufs* bufs);
 
 /* Where the results of the last gte_step / gte_reset live (device pointers). */

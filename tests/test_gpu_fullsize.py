@@ -86,17 +86,17 @@ def test_config4_total_size_on_one_gpu_vs_oracle(oracle_mod):
 
 
 def test_config3_full_size_rollout_paths_agree():
-    """65 536 envs x obs (20, 32): a rollout that keeps every observation (168 MB per step:
-    runs as separate launches), one that keeps only the last (fused kernel), one forced through
-    the fused kernel with observations (kernel_variant 256) and plain single steps must agree
-    bit for bit, episodes ending and restarting on the way."""
+    """65 536 envs x obs (20, 32): a rollout that keeps every observation (168 MB per step,
+    fused kernel, streaming stores), one that keeps only the last, one forced through separate
+    launches (kernel_variant 128) and plain single steps must agree bit for bit, episodes
+    ending and restarting on the way."""
     import torch
     from gym_trading_env_amd.batched import BatchedTradingEnv
     ds = _synthetic(1234, 100_000, 30, sigma=1e-3)
     N, K = 65_536, 12
     kw = dict(num_envs=N, seed=21, max_episode_duration=7, **C3)
     envs = [BatchedTradingEnv(ds, **kw), BatchedTradingEnv(ds, **kw),
-            BatchedTradingEnv(ds, kernel_variant=256, **kw), BatchedTradingEnv(ds, **kw)]
+            BatchedTradingEnv(ds, kernel_variant=128, **kw), BatchedTradingEnv(ds, **kw)]
     for e in envs:
         e.reset()
     gen = torch.Generator(device="cuda")
