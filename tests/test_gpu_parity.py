@@ -341,3 +341,36 @@ def test_same_step_final_observation(oracle_mod, windows, persist, output):
     env.close()
     with pytest.raises(ValueError, match="same_step"):
         BatchedTradingEnv((f, c), num_envs=4, autoreset="next_step", final_obs=True, output="numpy")
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_hip_vs_oracle_random_configurations(oracle_mod, seed):
+    """Random position sets, fees, interest rates, initial values, window lengths, feature
+    counts, durations, auto-reset modes and price volatility (calm to violent: the 0.7 drawdown
+    rule fires), several hundred envs each, against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    T = int(rng.integers(80, 500))
+    n_static = int(rng.integers(1, 40))
+    sigma = float(rng.choice([1e-3, 1e-2, 5e-2, 0.12]))
+    ds = [_synthetic(3000 + seed, T, n_static, sigma=sigma, drift=-sigma / 4)]
+    P = int(rng.integers(2, 9))
+    positions = sorted(set(np.round(rng.uniform(-2.5, 3.5, P), 2).tolist() + [0.0]))
+    windows = None if rng.random() < 0.25 else int(rng.integers(1, 30))
+    first = 0 if windows is None else windows - 1
+    room = T - 2 * first
+    if room < 12:
+        windows, first, room = 3, 2, T - 4
+    max_dur = "max" if rng.random() < 0.3 else int(rng.integers(3, max(4, room // 2)))
+    nd = int(rng.integers(0, 5))
+    kinds = [str(rng.choice(["last_position_taken", "real_position"])) for _ in range(nd)]
+    n = _compare_with_oracle(
+        oracle_mod, ds, n_envs=int(rng.integers(1, 700)), steps=40, seed=seed, check_every=4,
+        positions=positions, windows=windows, dynamic_feature_functions=kinds,
+        trading_fees=float(rng.choice([0.0, 1e-4, 1e-3, 1e-2])),
+        borrow_interest_rate=float(rng.choice([0.0, 3e-6, 1e-4, 1e-3])),
+        portfolio_initial_value=float(rng.choice([1000.0, 1.0, 1e6])),
+        initial_position="random" if rng.random() < 0.7 else positions[int(rng.integers(len(positions)))],
+        max_episode_duration=max_dur,
+        autoreset=[None, "next_step", "same_step"][int(rng.integers(3))],
+        dyn_persist=bool(rng.random() < 0.2))
+    assert n >= 0
