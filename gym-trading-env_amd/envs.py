@@ -83,7 +83,15 @@ class TradingEnv(_EnvBase):
         assert render_mode is None or render_mode in self.metadata["render_modes"]
         self.render_mode = render_mode
         self._device = device
-        resolve_dynamic_features(dynamic_feature_functions)  # refuses custom callables
+        # dynamic features the device knows run there; any other callable makes ALL of them
+        # host-side columns, evaluated over the History like the reference does (:153-154)
+        try:
+            resolve_dynamic_features(dynamic_feature_functions)
+            self._host_dyn = False
+        except NotImplementedError:
+            if not all(callable(f) for f in dynamic_feature_functions):
+                raise
+            self._host_dyn = True
         rname = getattr(reward_function, "__name__", reward_function)
         # a custom reward callable is evaluated on the host over the History (:265-267)
         self._host_reward = not (isinstance(reward_function, tuple) or rname in _REWARD_BY_NAME)
@@ -98,20 +106,28 @@ class TradingEnv(_EnvBase):
     def _set_df(self, df):
         self.df = df.copy()
         n_dyn = len(self.dynamic_feature_functions)
-        self._staged = staging.stage_dataframe(self.df, n_dyn=n_dyn, name=self.name)
+        # host-side dynamic features: the device holds the static columns only, the dynamic
+        # ones live in `_dyn_array` (the last columns of the reference's `_obs_array`)
+        self._staged = staging.stage_dataframe(self.df, n_dyn=0 if self._host_dyn else n_dyn,
+                                               name=self.name)
         self._features_columns = self._staged.feature_columns
         self._info_columns = self._staged.info_columns
         self._nb_static_features = self._staged.n_static
-        self._nb_features = self._staged.n_obs
+        self._nb_features = self._staged.n_static + n_dyn
         self._info_array = self._staged.info_array
         self._price_array = self._staged.close
+        if self._host_dyn:
+            if self._nb_static_features == 0:
+                raise NotImplementedError("custom dynamic features need at least one static "
+                                          "'feature' column in the DataFrame")
+            self._dyn_array = np.zeros((len(self.df), n_dyn), np.float32)
         if self._batch is not None:
             self._batch.close()
         # a fresh batch == a fresh `_obs_array` (dynamic columns zero); dyn_persist keeps
         # this env's in-place dynamic-feature writes across episodes like :153-154
         self._batch = BatchedTradingEnv(
             self._staged, num_envs=1, positions=self.positions,
-            dynamic_feature_functions=self.dynamic_feature_functions,
+            dynamic_feature_functions=[] if self._host_dyn else self.dynamic_feature_functions,
             reward_function="basic_reward_function" if self._host_reward else self.reward_function,
             windows=self.windows, trading_fees=self.trading_fees,
             borrow_interest_rate=self.borrow_interest_rate,
@@ -156,7 +172,17 @@ class TradingEnv(_EnvBase):
         return self.df.iloc[self._idx + delta]
 
     def _obs(self):
-        return self._last_obs
+        """`_get_obs` (:152-160).  Device-side dynamic features arrive inside the snapshot's
+        observation; host-side ones are evaluated over the History now, written in place at
+        row `_idx` (f32, they persist like the reference's) and appended to the static part."""
+        if not self._host_dyn:
+            return self._last_obs
+        t = self._idx
+        for i, fn in enumerate(self.dynamic_feature_functions):
+            self._dyn_array[t, i] = fn(self.historical_info)
+        if self.windows is None:
+            return np.concatenate([self._last_obs, self._dyn_array[t]])
+        return np.concatenate([self._last_obs, self._dyn_array[t + 1 - self.windows:t + 1]], axis=1)
 
     # -- reset (:163-199) ----------------------------------------------------------------
     def reset(self, seed=None, options=None, **kwargs):

@@ -140,8 +140,12 @@ def test_tradingenv_metrics_history_and_errors(tmp_path):
     assert {"open", "close", "portfolio_valuation", "position", "reward"} <= set(saved.columns)
     with pytest.raises(AssertionError):
         TradingEnv(df=df, positions=[0, 1], initial_position=0.5)
-    with pytest.raises(NotImplementedError):
-        TradingEnv(df=df, dynamic_feature_functions=[lambda h: 1.0])
+    with pytest.raises(NotImplementedError):  # names the device does not know, not callable
+        TradingEnv(df=df, dynamic_feature_functions=["no_such_feature"])
+    const = TradingEnv(df=df, dynamic_feature_functions=[lambda h: 1.0], verbose=0)  # host-side
+    obs, _ = const.reset()
+    assert obs[-1] == 1.0
+    const.close()
     env.close()
 
 
@@ -319,3 +323,58 @@ def test_read_env_snapshot_equals_separate_reads():
     with pytest.raises(Exception):
         env.read_env(N)
     env.close()
+
+
+def test_custom_dynamic_feature_callables_run_on_the_host():
+    """Arbitrary `dynamic_feature_functions` (docs/source/customization.rst) in the N=1 drop-in:
+    callables the device does not know are evaluated over the History on the host and written
+    in place like the reference's (:153-154).  Re-implementations of the two defaults under
+    other names must reproduce the device-side columns bit for bit; a third, really custom,
+    column is checked against its definition, window rows included."""
+    import pandas as pd
+    import gym_trading_env_amd as gte
+
+    def mine_position(history):
+        return history["position", -1]
+
+    def mine_real_position(history):
+        return history["real_position", -1]
+
+    def valuation_ratio(history):
+        return history["portfolio_valuation", -1] / 1000.0
+
+    rng = np.random.default_rng(8)
+    T = 400
+    close = 100 * np.exp(np.cumsum(rng.normal(0, 1e-2, T)))
+    df = pd.DataFrame({"close": close, "feature_a": rng.normal(0, 1, T),
+                       "feature_b": rng.normal(0, 1, T)})
+    kw = dict(df=df, positions=[-1, 0, 0.5, 1, 2], windows=6, trading_fees=1e-3,
+              borrow_interest_rate=1e-4, max_episode_duration=40, verbose=0)
+    builtin = gte.TradingEnv(**kw)
+    custom = gte.TradingEnv(dynamic_feature_functions=[mine_position, mine_real_position,
+                                                       valuation_ratio], **kw)
+    assert custom.observation_space.shape == (6, 5) and builtin.observation_space.shape == (6, 4)
+    for env in (builtin, custom):
+        np.random.seed(3)
+        env._trace = []
+        obs, _ = env.reset()
+        env._trace.append(obs.copy())
+        for k in range(150):
+            obs, reward, done, truncated, info = env.step(int(np.random.randint(5)))
+            env._trace.append(obs.copy())
+            if done or truncated:
+                obs, _ = env.reset()
+                env._trace.append(obs.copy())
+    assert len(builtin._trace) == len(custom._trace) > 150
+    for a, b in zip(builtin._trace, custom._trace):
+        assert b.dtype == np.float32
+        np.testing.assert_array_equal(a, b[:, :4])
+    # the custom column: current row = this step's valuation / 1000 (as f32); earlier window
+    # rows keep what was written when the env stood there (also by earlier episodes)
+    h = custom.historical_info
+    assert custom._trace[-1][-1, 4] == np.float32(h["portfolio_valuation", -1] / 1000.0)
+    assert custom._trace[-1][-2, 4] == np.float32(h["portfolio_valuation", -2] / 1000.0)
+    builtin.close()
+    custom.close()
+    with pytest.raises(NotImplementedError):  # the batch cannot call Python per env
+        gte.BatchedTradingEnv(df, num_envs=4, dynamic_feature_functions=[valuation_ratio])
