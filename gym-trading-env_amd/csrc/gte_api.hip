@@ -10,6 +10,7 @@
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -353,6 +354,10 @@ int gte_create(const gte_config* cfg, gte_env** out) {
           const int64_t wgs = ((int64_t)p.N + 4 * e - 1) / (4 * e);
           const int64_t rounds = (wgs + slots - 1) / slots;
           const double cost = (double)rounds * (10.0 + 2.0 * e * (double)vpe / 160.0);
+          if (getenv("GTE_DEBUG_GEOMETRY"))
+            fprintf(stderr, "[gte] envs/wave %2d: LDS %5zu B, %d workgroups/CU, %lld workgroups, "
+                            "%lld round(s), cost %.1f\n", e, smem, per_cu, (long long)wgs,
+                    (long long)rounds, cost);
           if (best == 0.0 || cost < best) { best = cost; epw = e; E->hot_per_cu = per_cu; }
         }
       }

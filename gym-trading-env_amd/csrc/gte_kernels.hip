@@ -53,55 +53,65 @@ enum { MODE_STEP = 0, MODE_RESET = 1 };
 #define GTE_STAMP(k) do {} while (0)
 #endif
 
+// The part of an env's record a step works on, in registers.  The fields only a reset touches
+// (episode, eps_on_ds, n_picks, q_head) stay in the record and are read / written there, inside
+// the rare reset branches: carried through the fp64 state machine they cost the step kernel
+// four more VGPRs, i.e. an occupancy step.
 struct EnvRegs {
-  int32_t idx, step, pos, dsi, start, episode, needs_reset, eps_on_ds, n_picks, q_head, lo_n;
+  int32_t idx, step, pos, dsi, start, needs_reset, lo_n;
   Portfolio q;
   double pv, realpos;
 };
 
 __device__ inline void load_state(const Params& p, int e, EnvRegs& s) {
-  const EnvRec r = p.rec[e];  // 128-byte aligned record: six 16-byte loads
-  s.idx = r.idx; s.step = r.step; s.pos = r.pos; s.dsi = r.dsi; s.start = r.start;
-  s.episode = r.episode; s.needs_reset = r.needs_reset; s.eps_on_ds = r.eps_on_ds;
-  s.n_picks = r.n_picks; s.q_head = r.q_head; s.lo_n = r.lo_n;
-  s.q.asset = r.asset; s.q.fiat = r.fiat; s.q.ia = r.ia; s.q.ifi = r.ifi;
-  s.pv = r.pv; s.realpos = r.realpos;
+  const EnvRec* r = &p.rec[e];  // 128-byte aligned record: six 16-byte loads
+  const int4* ri = reinterpret_cast<const int4*>(r);
+  const int4 a = ri[0];  // idx, step, pos, dsi
+  const int4 b = ri[1];  // start, (episode), needs_reset, (eps_on_ds)
+  const int4 c = ri[2];  // (n_picks), (q_head), lo_n, pad
+  s.idx = a.x; s.step = a.y; s.pos = a.z; s.dsi = a.w;
+  s.start = b.x; s.needs_reset = b.z; s.lo_n = c.z;
+  const double2* rd = reinterpret_cast<const double2*>(&r->asset);  // offset 48
+  const double2 d0 = rd[0], d1 = rd[1], d2 = rd[2];
+  s.q.asset = d0.x; s.q.fiat = d0.y; s.q.ia = d1.x; s.q.ifi = d1.y;
+  s.pv = d2.x; s.realpos = d2.y;
 }
 
+// start and lo_n are written where they change (do_reset, fill_limit_orders)
 __device__ inline void store_state(const Params& p, int e, const EnvRegs& s) {
-  EnvRec r;
-  r.idx = s.idx; r.step = s.step; r.pos = s.pos; r.dsi = s.dsi; r.start = s.start;
-  r.episode = s.episode; r.needs_reset = s.needs_reset; r.eps_on_ds = s.eps_on_ds;
-  r.n_picks = s.n_picks; r.q_head = s.q_head; r.lo_n = s.lo_n; r.pad0 = 0;
-  r.asset = s.q.asset; r.fiat = s.q.fiat; r.ia = s.q.ia; r.ifi = s.q.ifi;
-  r.pv = s.pv; r.realpos = s.realpos;
-  // only the 96 live bytes are written
-  uint4* dst = reinterpret_cast<uint4*>(&p.rec[e]);
-  const uint4* src = reinterpret_cast<const uint4*>(&r);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) dst[i] = src[i];
+  EnvRec* r = &p.rec[e];
+  *reinterpret_cast<int4*>(&r->idx) = make_int4(s.idx, s.step, s.pos, s.dsi);
+  r->needs_reset = s.needs_reset;
+  double2* d = reinterpret_cast<double2*>(&r->asset);
+  d[0] = make_double2(s.q.asset, s.q.fiat);
+  d[1] = make_double2(s.q.ia, s.q.ifi);
+  d[2] = make_double2(s.pv, s.realpos);
 }
 
 // MultiDatasetTradingEnv.next_dataset, environments.py:380-391
 __device__ inline void next_dataset(const Params& p, int e, int32_t inj_ds, EnvRegs& s,
                                     bool& fresh) {
-  const int32_t n = s.n_picks;
-  s.n_picks = n + 1;
+  EnvRec* r = &p.rec[e];
+  const int32_t n = r->n_picks;
+  r->n_picks = n + 1;
   s.dsi = (inj_ds >= 0) ? inj_ds : perm_pick(p, e, n / p.D, n % p.D);
-  s.eps_on_ds = 0;                  // :381
+  r->eps_on_ds = 0;                 // :381
   if (p.persist) fresh = true;      // _set_df rebuilds _obs_array (:135-141)
 }
 
 // TradingEnv.reset, environments.py:163-199 (+ MultiDataset reset :393-400)
 __device__ inline void do_reset(const Params& p, int e, int32_t inj_idx, int32_t inj_pos,
                                 int32_t inj_ds, EnvRegs& s, bool& fresh) {
+  EnvRec* rec = &p.rec[e];
   if (p.D > 1) {  // :394-398
-    s.eps_on_ds += 1;
-    if (s.eps_on_ds % p.switch_every == 0) next_dataset(p, e, inj_ds, s, fresh);
+    const int32_t eps = rec->eps_on_ds + 1;
+    rec->eps_on_ds = eps;  // (next_dataset, if it runs, clears it afterwards)
+    if (eps % p.switch_every == 0) next_dataset(p, e, inj_ds, s, fresh);
   }
   uint32_t r[4];
-  reset_draws(p, e, s.episode, 0x52534554u, r);
-  s.episode += 1;
+  const int32_t episode = rec->episode;
+  reset_draws(p, e, episode, 0x52534554u, r);
+  rec->episode = episode + 1;
   s.step = 0;  // :166
   s.lo_n = 0;  // :168 self._limit_orders = {}
   int32_t pi = p.init_pos_index;  // :167
@@ -116,6 +126,8 @@ __device__ inline void do_reset(const Params& p, int e, int32_t inj_idx, int32_t
   }
   s.idx = idx;
   s.start = idx;
+  rec->start = idx;
+  rec->lo_n = 0;
   const double position = p.positions[pi];  // TargetPortfolio, portfolio.py:59-66
   const double price = d.close[idx];
   s.q.asset = position * p.V0 / price;
@@ -132,14 +144,14 @@ __device__ inline void do_reset(const Params& p, int e, int32_t inj_idx, int32_t
 // [low, high] of the NEW row trades at the limit price, in insertion order.  A filled
 // non-persistent order is removed (the reference deletes it while iterating its dict
 // and raises RuntimeError; the intended behaviour is implemented).
-__device__ inline void fill_limit_orders(const Params& p, int e, const DatasetDesc& d,
+__device__ inline void fill_limit_orders(const Params& p, int e, const DatasetDesc* d,
                                          EnvRegs& s) {
   const int n = s.lo_n;
   if (n <= 0) return;
   int32_t* lp = p.lo_pos + (int64_t)e * p.P;
   double* ll = p.lo_limit + (int64_t)e * p.P;
   uint8_t* lper = p.lo_persist + (int64_t)e * p.P;
-  const double hi = d.high[s.idx], lo = d.low[s.idx];
+  const double hi = d->high[s.idx], lo = d->low[s.idx];
   int k = 0;
   for (int j = 0; j < n; ++j) {
     const int32_t pi = lp[j];
@@ -158,6 +170,7 @@ __device__ inline void fill_limit_orders(const Params& p, int e, const DatasetDe
     }
   }
   s.lo_n = k;
+  p.rec[e].lo_n = k;
 }
 
 #ifndef GTE_HOT_ONLY
@@ -186,9 +199,9 @@ __device__ inline void pop_injection(const Params& p, int e, EnvRegs& s, int32_t
                                      int32_t& qp, int32_t& qd) {
   qi = qp = qd = -1;
   if (p.q_n <= 0) return;
-  const int32_t h = s.q_head;
+  const int32_t h = p.rec[e].q_head;
   if (h >= p.q_n) return;
-  s.q_head = h + 1;
+  p.rec[e].q_head = h + 1;
   const int64_t k = (int64_t)e * p.q_n + h;
   if (p.q_idx) qi = p.q_idx[k];
   if (p.q_pos) qp = p.q_pos[k];
@@ -280,7 +293,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
       const int32_t ii = p.inj_idx ? p.inj_idx[e] : -1;
       const int32_t ip = p.inj_pos ? p.inj_pos[e] : -1;
       const int32_t id = p.inj_ds ? p.inj_ds[e] : -1;
-      if (p.D > 1 && s.n_picks == 0) next_dataset(p, e, id, s, fresh);  // ctor pick, :378
+      if (p.D > 1 && p.rec[e].n_picks == 0) next_dataset(p, e, id, s, fresh);  // ctor pick, :378
       do_reset(p, e, ii, ip, id, s, fresh);
       store_state(p, e, s);
       p.reward[e] = 0.0f; p.reward64[e] = 0.0;
@@ -324,24 +337,28 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
       }
     }
     if (stepped) {
-      const DatasetDesc d = p.ds[s.dsi];
+      // only the fields this path needs (the whole 40-byte descriptor held in registers
+      // across the fp64 state machine costs the kernel an occupancy step)
+      const DatasetDesc* dp = p.ds + s.dsi;
+      const double* d_close = dp->close;
+      const int32_t d_T = (int32_t)dp->T;
       if (action >= 0) {  // :234 -> :213-215: trade only when the position VALUE differs
         const double position = p.positions[action];
         if (position != p.positions[s.pos]) {
-          trade_to_position(s.q, position, d.close[s.idx], p.fees);  // :204-209
-          s.pos = action;                                             // :210
+          trade_to_position(s.q, position, d_close[s.idx], p.fees);  // :204-209
+          s.pos = action;                                            // :210
         }
       }
       s.idx += 1;   // :235
       s.step += 1;  // :236
-      if (p.lo_pos) fill_limit_orders(p, e, d, s);  // :238
-      const double price = d.close[s.idx];  // :239
+      if (p.lo_pos) fill_limit_orders(p, e, dp, s);  // :238
+      const double price = d_close[s.idx];  // :239
       GTE_STAMP(3);  // descriptor, positions, trade, price at the new row arrived
       s.q.ia = pymax0(-s.q.asset) * p.rate;   // update_interest, portfolio.py:44-46
       s.q.ifi = pymax0(-s.q.fiat) * p.rate;
       const double pv = valorisation(s.q, price);  // :241
       const bool done = (pv / p.V0) <= 0.7;        // :246
-      bool trunc = s.idx >= (int32_t)d.T - 1;      // :248
+      bool trunc = s.idx >= d_T - 1;               // :248
       if (p.max_dur > 0 && s.step >= p.max_dur - 1) trunc = true;  // :250
       s.realpos = (s.q.asset - s.q.ia) * price / valorisation(s.q, price);  // :259
       double rew = 0.0;                            // :263, stays 0 when done (:265)
