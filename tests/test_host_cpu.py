@@ -145,3 +145,42 @@ def test_golden_fixtures_are_data_only():
         assert "obs" in z.files and "cfg_json" in z.files
     z = np.load(os.path.join(replay.GOLDEN_DIR, "portfolio_random.npz"), allow_pickle=False)
     assert z["inputs"].shape == (3000, 9) and z["outputs"].shape == (3000, 6)
+
+
+def _resource_usage(source):
+    """VGPRs / scratch / occupancy per kernel from hipcc's resource-usage remarks (gfx950)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "gym-trading-env_amd", "csrc")
+    with tempfile.TemporaryDirectory() as tmp:
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                            "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(ROOT, "include"),
+                            "-c", os.path.join(csrc, source), "-o", os.path.join(tmp, "x.o"),
+                            "-Rpass-analysis=kernel-resource-usage"],
+                           capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = []
+    for block in r.stderr.split("Function Name:")[1:]:
+        get = lambda key: int(re.search(key + r":\s*(\d+)", block).group(1))
+        out.append({"name": block.split()[0], "vgprs": get("VGPRs"),
+                    "scratch": get(r"ScratchSize \[bytes/lane\]"),
+                    "occupancy": get(r"Occupancy \[waves/SIMD\]")})
+    assert out, r.stderr[-2000:]
+    return out
+
+
+@pytest.mark.parametrize("source,min_occupancy", [("gte_hot.hip", 6), ("gte_hot_nt.hip", 6),
+                                                  ("gte_rollout.hip", 4)])
+def test_kernel_register_budget(source, min_occupancy):
+    """The step kernel's speed hangs on its register allocation: one occupancy step costs
+    10+ us per step, and scratch use doubles the store traffic.  A change to the
+    shared device code that pushes the hot instantiations over their budget fails here, on the
+    CPU, before anything is measured."""
+    for k in _resource_usage(source):
+        assert k["scratch"] == 0, k
+        assert k["occupancy"] >= min_occupancy, k
