@@ -23,6 +23,16 @@ def shard_range(global_envs: int, world: int, rank: int) -> tuple[int, int]:
     return first, base + (1 if rank < rem else 0)
 
 
+def shard_datasets(n_datasets: int, world: int, rank: int) -> range:
+    """Indices of the datasets `rank` keeps resident when the symbols are PARTITIONED over the
+    ranks (config 5: 1 024 symbols, 128 per GPU): a contiguous block, like the env shards, so
+    that envs and the tables they read sit on the same GPU and dataset switching stays local."""
+    first, count = shard_range(n_datasets, world, rank)
+    if count == 0:
+        raise ValueError(f"{n_datasets} datasets cannot be partitioned over {world} ranks")
+    return range(first, first + count)
+
+
 def packed_layout(n: int) -> dict:
     """Byte ranges of the packed per-step return of a shard of n envs."""
     return {"reward": (0, 4 * n), "terminated": (4 * n, 5 * n), "truncated": (5 * n, 6 * n),
@@ -191,13 +201,20 @@ class ShardedTradingEnv:
 
     step() returns the LOCAL observations (device resident) and the GLOBAL reward /
     terminated / truncated ([world, n_local] views); `gather_obs=True` also returns the
-    global observations instead of the local ones."""
+    global observations instead of the local ones.  Datasets are replicated on every rank
+    unless `partition_datasets=True` (then rank r keeps block r of the list, and its envs
+    only ever visit those)."""
 
     def __init__(self, df, global_envs: int, *, group=None, device=None, gather_obs=False,
-                 pipeline=1, block=1, **kw):
+                 pipeline=1, block=1, partition_datasets=False, **kw):
         from .batched import BatchedTradingEnv
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if partition_datasets:  # config 5: each rank keeps only its block of the symbols
+            if not isinstance(df, (list, tuple)) or len(df) < self.world:
+                raise ValueError("partition_datasets needs a list of at least `world` datasets")
+            self.dataset_indices = shard_datasets(len(df), self.world, self.rank)
+            df = [df[i] for i in self.dataset_indices]
         if global_envs % self.world:
             raise ValueError("global_envs must be a multiple of the world size")
         self.first, self.n_local = shard_range(global_envs, self.world, self.rank)

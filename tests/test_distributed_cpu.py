@@ -157,6 +157,16 @@ def test_block_pipeline_two_ranks_equals_unsharded(tmp_path, oracle_mod, block, 
         np.testing.assert_array_equal(got["trunc"][k], env.truncated.astype(bool))
 
 
+def test_shard_datasets_partitions_the_symbols():
+    from gym_trading_env_amd.distributed import shard_datasets
+    for n, w in ((1024, 8), (10, 3), (8, 8)):
+        blocks = [list(shard_datasets(n, w, r)) for r in range(w)]
+        assert sum(blocks, []) == list(range(n)) and all(blocks)
+    assert list(shard_datasets(1024, 8, 3)) == list(range(384, 512))
+    with pytest.raises(ValueError):
+        shard_datasets(3, 4, 3)
+
+
 def test_shard_range_partitions_all_envs():
     from gym_trading_env_amd.distributed import shard_range
     for g, w in ((262144, 8), (10, 3), (7, 8), (65536, 1)):
