@@ -719,6 +719,9 @@ __device__ inline void final_windows(const Params& p, const WgLds& L, int s_firs
 //       ~3 000 cycles of fp64 per wave whatever the number of active lanes); otherwise
 //       every wave runs phase A for its own EPW envs.
 // STAGE: how the dynamic-column values reach the copy loop (STAGE_* above).
+#ifndef GTE_GATHER_U
+#define GTE_GATHER_U 4  // independent 16-byte loads in flight per lane in the gather
+#endif
 template <int MODE, int VEC, int NT, bool COOP, int STAGE>
 __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t vpe_magic,
                                                   const uint64_t fv_magic,
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  phase_b<VEC, NT, STAGE, 4>(p, L, s_first, n_env, lane, vpe_magic, fv_magic);
+  phase_b<VEC, NT, STAGE, GTE_GATHER_U>(p, L, s_first, n_env, lane, vpe_magic, fv_magic);
   GTE_STAMP(7);
   if (MODE == MODE_STEP && p.final_obs) final_windows<VEC>(p, L, s_first, n_env, lane, fv_magic);
 }
