@@ -170,6 +170,8 @@ SYMBOLS = {
     "gte_bind_outputs": (C.c_int, [C.c_void_p, _P(GteOutputs)]),
     "gte_read_env": (C.c_int, [C.c_void_p, C.c_int32, _P(GteEnvSnapshot), C.c_void_p]),
     "gte_read_envs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gte_read_envs_view": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                     _P(C.c_void_p), _P(C.c_void_p)]),
     "gte_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, _P(GteRolloutBufs)]),
     "gte_bind_returns": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gte_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -141,7 +141,7 @@ class BatchedTradingEnv(_VectorEnvBase):
                  episodes_between_dataset_switch=1, dyn_persist=False, seed=0,
                  env_id_base=0, device=0, output="torch", envs_per_wave=0,
                  nontemporal_obs=3, kernel_variant=0, library_path=None, debug_flags=0,
-                 affinity_period=0, final_obs=False, log_steps=0, return_slots=1):
+                 affinity_period=0, final_obs=False, log_steps=0, return_slots=1, copy=True):
         assert render_mode is None or render_mode in self.metadata["render_modes"]
         if output not in ("torch", "numpy"):
             raise ValueError("output must be 'torch' or 'numpy'")
@@ -154,6 +154,10 @@ class BatchedTradingEnv(_VectorEnvBase):
         # row t % K of one [K, 6N] buffer, so a collective still reading older returns is not
         # overwritten by the next K-1 steps, and runs of consecutive steps are contiguous
         # blocks (distributed.ReturnPipeline gathers them a block at a time)
+        # copy=False (output="numpy", Gymnasium's vector-env convention): step()/reset() return
+        # views of the library's pinned staging buffer, overwritten by the next call — no
+        # 168 MB allocation + copy per step at the headline shape
+        self.copy = bool(copy)
         self.return_slots = int(return_slots)
         if self.return_slots < 1 or (self.return_slots > 1 and output != "torch"):
             raise ValueError("return_slots must be >= 1 (and > 1 only with output='torch')")
@@ -426,7 +430,7 @@ class BatchedTradingEnv(_VectorEnvBase):
             t = self._t
             return t["obs"], t["reward"], t["terminated"], t["truncated"]
         # host arrays: state, returns and observations of the whole batch in ONE transfer
-        self._snap, self._snap_obs = self.read_envs()
+        self._snap, self._snap_obs = self.read_envs(view=not self.copy)
         self._snap_epoch = self._epoch
         snap = self._snap
         return (self._snap_obs, np.ascontiguousarray(snap["reward"]),
@@ -517,12 +521,25 @@ class BatchedTradingEnv(_VectorEnvBase):
             _abi.check(self._lib, self._lib.gte_step(self._h, a.ctypes.data, 0))
         self._epoch += 1
 
-    def read_envs(self, first: int = 0, count=None, with_obs: bool = True):
+    def read_envs(self, first: int = 0, count=None, with_obs: bool = True, view: bool = False):
         """(snapshots, obs): a structured array [count] with the fields of struct
         gte_env_snapshot (state, reward f64, terminated, truncated) and the observations
         [count, *obs_shape] (or None) of envs first..first+count-1, fetched with one
-        device->host transfer (`gte_read_envs`)."""
+        device->host transfer (`gte_read_envs`).  view=True: arrays over the library's pinned
+        staging buffer, valid until the next read (`gte_read_envs_view`)."""
         count = self.num_envs - first if count is None else int(count)
+        if view:
+            ps, po = C.c_void_p(), C.c_void_p()
+            _abi.check(self._lib, self._lib.gte_read_envs_view(
+                self._h, int(first), count, 1 if with_obs else 0, C.byref(ps), C.byref(po)))
+            snap = np.frombuffer((C.c_char * (96 * count)).from_address(ps.value),
+                                 dtype=_abi.SNAPSHOT_DTYPE)
+            obs = None
+            if with_obs:
+                n = count * int(np.prod(self.obs_shape))
+                obs = np.frombuffer((C.c_float * n).from_address(po.value), dtype=np.float32
+                                    ).reshape((count,) + self.obs_shape)
+            return snap, obs
         snap = np.empty(count, dtype=_abi.SNAPSHOT_DTYPE)
         obs = np.empty((count,) + self.obs_shape, np.float32) if with_obs else None
         _abi.check(self._lib, self._lib.gte_read_envs(

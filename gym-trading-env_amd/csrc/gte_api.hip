@@ -126,6 +126,7 @@ struct gte_env {
   bool store_auto = false; // the observation store policy was chosen here (cfg said 3)
   void* h_snap = nullptr;  // pinned host memory for gte_read_envs: snapshots, then observations
   size_t h_snap_bytes = 0;
+  bool view_reads = false; // gte_read_envs_view has been used: the buffer is kept at full size
 };
 
 template <typename T>
@@ -819,28 +820,50 @@ int gte_bind_outputs(gte_env* E, const gte_outputs* b) {
 
 static_assert(sizeof(gte_env_snapshot) == 96, "gte_env_snapshot layout");
 
-int gte_read_envs(gte_env* E, int32_t first, int32_t count, gte_env_snapshot* out, float* obs) {
+static int read_envs_impl(gte_env* E, int32_t first, int32_t count, int32_t want_obs,
+                          const gte_env_snapshot** out, const float** obs, bool hands_out_views) {
   if (!E || !out) return fail(GTE_ERR_INVALID, "NULL argument");
   if (!E->was_reset) return fail(GTE_ERR_STATE, "gte_read_envs before gte_reset");
   if (first < 0 || count < 1 || (int64_t)first + count > E->p.N)
     return fail(GTE_ERR_INVALID, "envs %d..%lld out of range", first, (long long)first + count - 1);
+  if (want_obs && !obs) return fail(GTE_ERR_INVALID, "obs is NULL");
   HIPCHK(hipSetDevice(E->cfg.device));
   const size_t elems = (size_t)E->p.W * (size_t)E->p.Fobs;
   const size_t head = sizeof(gte_env_snapshot) * (size_t)count;  // 96 B each: 16-byte aligned
-  const size_t need = head + (obs ? sizeof(float) * elems * (size_t)count : 0);
-  if (need > E->h_snap_bytes) {  // pinned and mapped: the kernel writes host memory directly
+  const size_t need = head + (want_obs ? sizeof(float) * elems * (size_t)count : 0);
+  // Callers may hold views into the staging buffer: once it exists at full size it is never
+  // reallocated, so size it for the whole batch the first time a buffer is made.
+  const size_t full = (sizeof(gte_env_snapshot) + sizeof(float) * elems) * (size_t)E->p.N;
+  if (hands_out_views) E->view_reads = true;
+  const size_t want = E->view_reads ? full : need;
+  if (want > E->h_snap_bytes) {  // pinned and mapped: the kernel writes host memory directly
     if (E->h_snap) HIPCHK(hipHostFree(E->h_snap));
     E->h_snap = nullptr; E->h_snap_bytes = 0;
-    HIPCHK(hipHostMalloc(&E->h_snap, need, hipHostMallocMapped));
-    E->h_snap_bytes = need;
+    HIPCHK(hipHostMalloc(&E->h_snap, want, hipHostMallocMapped));
+    E->h_snap_bytes = want;
   }
   float* h_obs = (float*)((char*)E->h_snap + head);
   HIPCHK(gte::launch_snapshot(E->p.rec, E->p.reward64, E->p.terminated, E->p.truncated, E->p.obs,
-                              (int64_t)elems, first, count, E->h_snap, obs ? h_obs : nullptr,
+                              (int64_t)elems, first, count, E->h_snap, want_obs ? h_obs : nullptr,
                               E->stream));
   HIPCHK(hipStreamSynchronize(E->stream));
-  memcpy(out, E->h_snap, head);
-  if (obs) memcpy(obs, h_obs, sizeof(float) * elems * (size_t)count);
+  *out = (const gte_env_snapshot*)E->h_snap;
+  if (obs) *obs = want_obs ? h_obs : nullptr;
+  return GTE_OK;
+}
+
+int gte_read_envs_view(gte_env* E, int32_t first, int32_t count, int32_t want_obs,
+                       const gte_env_snapshot** out, const float** obs) {
+  return read_envs_impl(E, first, count, want_obs, out, obs, true);
+}
+
+int gte_read_envs(gte_env* E, int32_t first, int32_t count, gte_env_snapshot* out, float* obs) {
+  if (!out) return fail(GTE_ERR_INVALID, "NULL argument");
+  const gte_env_snapshot* snaps = nullptr;
+  const float* h_obs = nullptr;
+  TRY(read_envs_impl(E, first, count, obs ? 1 : 0, &snaps, &h_obs, false));
+  memcpy(out, snaps, sizeof(gte_env_snapshot) * (size_t)count);
+  if (obs) memcpy(obs, h_obs, sizeof(float) * (size_t)E->p.W * (size_t)E->p.Fobs * (size_t)count);
   return GTE_OK;
 }
 

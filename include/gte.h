@@ -302,6 +302,13 @@ typedef struct gte_env_snapshot {
  * `obs` (count * W*F_obs floats) may be NULL.  This is what the host-array ("numpy") mode of
  * the Python classes calls once per step instead of one copy per field. */
 int gte_read_envs(gte_env* env, int32_t first, int32_t count, gte_env_snapshot* out, float* obs);
+/* The same without the final copy: *out / *obs point INTO the library's pinned host staging
+ * buffer (`count` snapshots; `count` * W*F_obs floats, or NULL when want_obs == 0) and stay
+ * valid until the next gte_read_envs / gte_read_envs_view / gte_read_env / gte_destroy on this
+ * env.  For host-array consumers that can live with buffers being reused every step (what
+ * Gymnasium's vector envs call copy=False). */
+int gte_read_envs_view(gte_env* env, int32_t first, int32_t count, int32_t want_obs,
+                       const gte_env_snapshot** out, const float** obs);
 /* gte_read_envs for one env (the N=1 drop-in TradingEnv's per-step call). */
 int gte_read_env(gte_env* env, int32_t env_index, gte_env_snapshot* out, float* obs);
 

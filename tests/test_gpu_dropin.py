@@ -378,3 +378,37 @@ def test_custom_dynamic_feature_callables_run_on_the_host():
     custom.close()
     with pytest.raises(NotImplementedError):  # the batch cannot call Python per env
         gte.BatchedTradingEnv(df, num_envs=4, dynamic_feature_functions=[valuation_ratio])
+
+
+def test_copy_false_returns_views_of_the_staging_buffer():
+    """output="numpy", copy=False (Gymnasium's vector-env convention): the same values as
+    copy=True, delivered as views that the next call overwrites."""
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    rng = np.random.default_rng(6)
+    T, N = 300, 300
+    close = 100 * np.exp(np.cumsum(rng.normal(0, 2e-2, T)))
+    feat = rng.normal(0, 1, (T, 2)).astype(np.float32)
+    kw = dict(num_envs=N, positions=[-1, 0, 1], windows=5, trading_fees=1e-3,
+              max_episode_duration=12, output="numpy", seed=4)
+    a = BatchedTradingEnv((feat, close), copy=True, **kw)
+    b = BatchedTradingEnv((feat, close), copy=False, **kw)
+    oa, _ = a.reset()
+    ob, _ = b.reset()
+    np.testing.assert_array_equal(oa, ob)
+    assert ob.base is not None and oa.flags.owndata  # a view of foreign memory vs an own array
+    first_view = ob
+    first_copy = ob.copy()
+    # small reads in between must not move the staging buffer under the views
+    snap, one = b.read_env(7)
+    np.testing.assert_array_equal(one, first_copy[7])
+    for k in range(30):
+        act = rng.integers(-1, 3, N).astype(np.int32)
+        ra = a.step(act)
+        rb = b.step(act)
+        for x, y in zip(ra[:4], rb[:4]):
+            np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(a.state("portfolio_valuation"), b.state("portfolio_valuation"))
+        assert rb[0].ctypes.data == first_view.ctypes.data  # same buffer every step
+    assert not np.array_equal(first_view, first_copy)  # the old view shows the new step
+    a.close()
+    b.close()
