@@ -634,7 +634,11 @@ int gte_rollout(gte_env* E, const int32_t* actions, int32_t n_steps, const gte_r
   const bool fused = E->vec == 4 && E->coop && E->stage == 1 && !E->overlap && !E->cfg.final_obs &&
                      E->cfg.log_steps == 0 && !(E->cfg.kernel_variant & 128);
   // per-step observation rows are written once and not read back by the kernels: a stream
-  const int store_keep = E->cfg.nontemporal_obs;
+  struct RestoreStorePolicy {  // whatever path leaves this function, the env's policy returns
+    int32_t& slot;
+    int32_t value;
+    ~RestoreStorePolicy() { slot = value; }
+  } restore_store_policy{E->cfg.nontemporal_obs, E->cfg.nontemporal_obs};
   if (b->obs && E->store_auto) E->cfg.nontemporal_obs = 1;
   if (!fused) {
     // same results, one launch per step: point the step kernel at row k of every buffer
@@ -657,7 +661,7 @@ int gte_rollout(gte_env* E, const int32_t* actions, int32_t n_steps, const gte_r
     }
     E->p.obs = keep.obs; E->p.reward = keep.reward; E->p.reward64 = keep.reward64;
     E->p.terminated = keep.terminated; E->p.truncated = keep.truncated;
-    if (rc != GTE_OK) { E->cfg.nontemporal_obs = store_keep; return rc; }
+    if (rc != GTE_OK) return rc;
   } else {
     if (E->affinity_period > 0) {
       E->steps_since_rebuild += n_steps;
@@ -697,12 +701,8 @@ int gte_rollout(gte_env* E, const int32_t* actions, int32_t n_steps, const gte_r
                           b->truncated, b->valuation};
     const hipError_t le = gte::launch_rollout(p, r, E->cfg.nontemporal_obs, r_blocks, E->threads,
                                               E->stream);
-    if (le != hipSuccess) {
-      E->cfg.nontemporal_obs = store_keep;
-      return fail(GTE_ERR_HIP, "rollout launch: %s", hipGetErrorString(le));
-    }
+    if (le != hipSuccess) return fail(GTE_ERR_HIP, "rollout launch: %s", hipGetErrorString(le));
   }
-  E->cfg.nontemporal_obs = store_keep;
   // the env's own return buffers describe the last step
   const size_t last = (size_t)(n_steps - 1) * N;
   if (b->reward) HIPCHK(hipMemcpyAsync(E->p.reward, b->reward + last, 4 * N, hipMemcpyDeviceToDevice, E->stream));
