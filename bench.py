@@ -281,6 +281,12 @@ def main():
                          "algorithmic_bytes_per_env_step": b_alg,
                          "kernel_us_per_launch": kernel_us},
         }
+        if traffic:
+            # `achieved` prices ALGORITHMIC bytes (SURVEY §8d credits no reuse of the feature
+            # table between envs or steps), so with the table served from L2 it can pass the
+            # HBM peak; the counter-measured bytes per launch over the same kernel time:
+            out["roofline"]["traffic_rate"] = traffic / (kernel_us * 1e-6) / 1e9
+            out["roofline"]["traffic_frac"] = out["roofline"]["traffic_rate"] / HBM_PEAK_GBS
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
             # the reference's OWN Python step() cannot run on this box (its files do not
