@@ -9,7 +9,7 @@ Heavy imports (torch, the HIP library) happen on first use, not here.
 from . import _abi, config, staging  # noqa: F401
 from ._abi import GteError  # noqa: F401
 
-__all__ = ["TradingEnv", "MultiDatasetTradingEnv", "BatchedTradingEnv", "GteError",
+__all__ = ["TradingEnv", "MultiDatasetTradingEnv", "BatchedTradingEnv", "SB3TradingVecEnv", "GteError",
            "basic_reward_function", "dynamic_feature_last_position_taken",
            "dynamic_feature_real_position"]
 
@@ -18,6 +18,7 @@ _LAZY = {
     "MultiDatasetTradingEnv": "envs", "basic_reward_function": "envs",
     "dynamic_feature_last_position_taken": "envs",
     "dynamic_feature_real_position": "envs", "History": "history",
+    "SB3TradingVecEnv": "sb3",
 }
 
 

@@ -412,3 +412,48 @@ def test_copy_false_returns_views_of_the_staging_buffer():
     assert not np.array_equal(first_view, first_copy)  # the old view shows the new step
     a.close()
     b.close()
+
+
+def test_sb3_vecenv_adapter_against_single_envs():
+    """SB3's VecEnv contract (reset -> obs; step_async/step_wait -> obs, rewards, dones, infos;
+    self-resetting envs with infos[i]['terminal_observation'] / ['TimeLimit.truncated']) over
+    the batch, checked against the oracle driven the same way."""
+    import gym_trading_env_amd as gte
+    from gym_trading_env_amd.config import make_config
+    from oracle import oracle
+    rng = np.random.default_rng(11)
+    T, N = 400, 96
+    close = 100 * np.exp(np.cumsum(rng.normal(-2e-3, 4e-2, T)))  # drawdowns happen
+    feat = rng.normal(0, 1, (T, 3)).astype(np.float32)
+    kw = dict(positions=[-1, 0, 1, 2], windows=4, trading_fees=1e-3, borrow_interest_rate=1e-4,
+              max_episode_duration=25, seed=6)
+    vec = gte.SB3TradingVecEnv((feat, close), N, **kw)
+    full = np.zeros((T, 5), np.float32)
+    full[:, :3] = feat
+    ora = oracle.OracleEnv(make_config(n_envs=N, n_static=3, autoreset="same_step", final_obs=True,
+                                       **kw), [(full, close)])
+    obs = vec.reset()
+    ora.reset()
+    assert obs.shape == (N, 4, 5) and vec.observation_space.shape == (4, 5)
+    np.testing.assert_array_equal(obs, ora.obs)
+    seen_term = seen_trunc = 0
+    for k in range(80):
+        a = rng.integers(0, 4, N)
+        vec.step_async(a)
+        obs, rewards, dones, infos = vec.step_wait()
+        ora.step(a.astype(np.int32))
+        np.testing.assert_array_equal(obs, ora.obs)
+        np.testing.assert_array_equal(rewards, ora.reward)
+        np.testing.assert_array_equal(dones, (ora.terminated | ora.truncated).astype(bool))
+        assert rewards.dtype == np.float32 and len(infos) == N
+        for e in range(N):
+            assert ("terminal_observation" in infos[e]) == bool(dones[e])
+            if dones[e]:
+                np.testing.assert_array_equal(infos[e]["terminal_observation"], ora.final_obs[e])
+                assert infos[e]["TimeLimit.truncated"] == bool(ora.truncated[e] and not ora.terminated[e])
+                seen_term += int(ora.terminated[e])
+                seen_trunc += int(ora.truncated[e] and not ora.terminated[e])
+            assert infos[e]["portfolio_valuation"] == ora.state()["portfolio_valuation"][e]
+    assert seen_term > 0 and seen_trunc > 0
+    assert vec.env_is_wrapped(object) == [False] * N and vec.get_attr("num_envs", [0, 1]) == [N, N]
+    vec.close()
