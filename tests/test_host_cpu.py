@@ -184,3 +184,18 @@ def test_kernel_register_budget(source, min_occupancy):
     for k in _resource_usage(source):
         assert k["scratch"] == 0, k
         assert k["occupancy"] >= min_occupancy, k
+
+
+def test_integration_md_stub_matches_the_abi():
+    """The ctypes stub INTEGRATION.md shows a maintainer of the reference is not prose: its
+    gte_config must have the fields, order and size of the real one."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = text.split("```python")[1].split("```")[0]
+    code = code.split('lib = C.CDLL("libgte.so")')[0]  # the struct, not the load
+    scope = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), scope)  # our own document
+    stub = scope["gte_config"]
+    assert [f[0] for f in stub._fields_] == [f[0] for f in _abi.GteConfig._fields_]
+    assert C.sizeof(stub) == C.sizeof(_abi.GteConfig)
+    for (name, a), (_, b) in zip(stub._fields_, _abi.GteConfig._fields_):
+        assert C.sizeof(a) == C.sizeof(b), name
