@@ -143,8 +143,8 @@ class ReturnPipeline:
     next block; a block is waited for only when its rows are about to be rewritten, `depth`
     blocks later.  Per step this costs no cross-stream dependency and no host work except on
     block boundaries (measured on one MI355X with a 1-rank RCCL group, config 3: synchronous
-    per-step gather 51 us/step, per-step asynchronous 58-68 us/step — host and cross-stream
-    bound —, block=16 43.9 us/step, no gather 42.4 us/step; profiles/r01_gather_rehearsal.md).
+    per-step gather 48 us/step, per-step asynchronous 58-68 us/step — host and cross-stream
+    bound —, block=16 41.7 us/step, no gather 39.1 us/step; profiles/r01_gather_rehearsal.md).
     block=1, depth>=2 is the per-step form."""
 
     def __init__(self, env, returns: ReturnGather, block: int, depth: int):
