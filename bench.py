@@ -17,7 +17,7 @@ timed on this box's host cores on a bounded sample of the same workload.
 Multi-GPU (torchrun, one rank per GPU): envs shard with no data-path collective
 except the RCCL all-gather of the returns (reward, terminated, truncated: 6 bytes
 per env and step), which is what the north star names.  Every step's returns cross
-xGMI inside the timed region, a --gather-every (16) step block at a time on RCCL's
+xGMI inside the timed region, a --gather-every (32) step block at a time on RCCL's
 stream while the following steps run (DESIGN.md §6 has the per-step alternatives
 measured); --gather-obs adds the observation all-gather (xGMI-bound, SURVEY §7
 hard part 7).  Weak scaling: 65 536 envs/GPU.
@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--affinity", type=int, default=0,
                     help="L2-affinity re-sort period in steps (0 = default 128, -1 = off)")
     ap.add_argument("--gather-obs", action="store_true", help="also all-gather observations (N>1)")
-    ap.add_argument("--gather-every", type=int, default=16,
+    ap.add_argument("--gather-every", type=int, default=32,
                     help="N>1: all-gather the returns in blocks of this many steps (every step's "
                          "reward/flags still cross xGMI inside the timed region; 1 = per step)")
     ap.add_argument("--gather-depth", type=int, default=2,
@@ -199,7 +199,7 @@ def main():
 
     # the return of a sharded run: RCCL all-gather of the packed (reward f32 | terminated u8 |
     # truncated u8) records, 6 bytes per env and step, which the kernel writes directly in
-    # that layout; by default a 16-step block at a time, overlapping the following steps
+    # that layout; by default a 32-step block at a time, overlapping the following steps
     returns = pipe = None
     if use_dist:
         from gym_trading_env_amd.distributed import ReturnGather, ReturnPipeline

@@ -260,6 +260,16 @@ class BatchedTradingEnv(_VectorEnvBase):
             self._packed_all = torch.zeros((self.return_slots, 6 * N), dtype=torch.uint8,
                                            device=dev)
             self._packed = list(self._packed_all.unbind(0))
+            # per slot, made once: the buffer, its (reward, terminated, truncated) views and
+            # the three device pointers gte_bind_returns takes
+            self._slot_views = []
+            for buf in self._packed:
+                base = buf.data_ptr()
+                self._slot_views.append((
+                    buf,
+                    (buf[:4 * N].view(torch.float32), buf[4 * N:5 * N].view(torch.bool),
+                     buf[5 * N:].view(torch.bool)),
+                    (C.c_void_p(base), C.c_void_p(base + 4 * N), C.c_void_p(base + 5 * N))))
             # outputs start bound to row 0 (reset writes there); the first step rotates to it
             self._ret_slot = self.return_slots - 1
             self.packed_returns = self._packed[0]
@@ -401,18 +411,13 @@ class BatchedTradingEnv(_VectorEnvBase):
 
     def _rotate_returns(self):
         """Point the next step at the next packed return buffer (gte_bind_returns)."""
-        N = self.num_envs
         self._ret_slot = (self._ret_slot + 1) % self.return_slots
-        buf = self._packed[self._ret_slot]
-        base = buf.data_ptr()
-        _abi.check(self._lib, self._lib.gte_bind_returns(
-            self._h, C.c_void_p(base), C.c_void_p(base + 4 * N), C.c_void_p(base + 5 * N)))
+        buf, views, ptrs = self._slot_views[self._ret_slot]
+        _abi.check(self._lib, self._lib.gte_bind_returns(self._h, *ptrs))
         self.packed_returns = buf
-        self._out.reward, self._out.terminated, self._out.truncated = base, base + 4 * N, base + 5 * N
+        self._out.reward, self._out.terminated, self._out.truncated = (p.value for p in ptrs)
         t = self._t
-        t["reward"] = buf[:4 * N].view(self._torch.float32)
-        t["terminated"] = buf[4 * N:5 * N].view(self._torch.bool)
-        t["truncated"] = buf[5 * N:].view(self._torch.bool)
+        t["reward"], t["terminated"], t["truncated"] = views
 
     @property
     def return_slot(self) -> int:
