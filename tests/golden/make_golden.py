@@ -426,6 +426,37 @@ def portfolio_vectors():
     print("portfolio_random:", n, "vectors")
 
 
+def custom_callables_trace():
+    """hostcb_custom_callables.npz: custom Python `dynamic_feature_functions` and
+    `reward_function` (docs/source/customization.rst) run INSIDE the reference.  The batch
+    cannot run Python per env, so this fixture is replayed by the N=1 drop-in only
+    (tests/test_gpu_dropin.py); the callables live in tests/custom_callables.py."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import custom_callables as cc
+    from gym_trading_env.environments import dynamic_feature_last_position_taken
+    rng = np.random.default_rng(424242)
+    feat, close = random_walk(31, 260, 3, sigma=1.5e-2)
+    df = make_df(feat, close)
+    cfg = base_cfg(positions=[-1, 0, 0.5, 1, 2], windows=4, trading_fees=1e-3,
+                   borrow_interest_rate=1e-4, max_episode_duration=40,
+                   reward_function=["custom", "reward_simple_return_minus_turnover"],
+                   dynamic_feature_functions=["last_position_taken", "custom:dyn_valuation_ratio",
+                                              "custom:dyn_exposure_change"],
+                   dyn_persist=True)
+    rec = run_trace(lambda e: TradingEnv(
+        df=df, reward_function=cc.reward_simple_return_minus_turnover,
+        dynamic_feature_functions=[dynamic_feature_last_position_taken, cc.dyn_valuation_ratio,
+                                   cc.dyn_exposure_change], **ref_kwargs(cfg)),
+        cfg["positions"], n_envs=3, n_calls=300, action_rng=rng, seed_base=5150)
+    save("hostcb_custom_callables", cfg, [(feat, close)], rec,
+         "custom dynamic features and a custom reward evaluated by the reference over its "
+         "History; same env object across episodes (in-place dynamic columns persist)")
+
+
 if __name__ == "__main__":
+    if "--only-custom" in sys.argv:
+        custom_callables_trace()
+        sys.exit(0)
     main()
     portfolio_vectors()
+    custom_callables_trace()

@@ -23,9 +23,11 @@ STATE_I32 = {"idx": "idx", "step": "step", "pos_index": "position_index",
 
 
 def golden_names():
-    """Names of the trace fixtures (portfolio_random.npz is a known-answer table, not a trace)."""
+    """Names of the trace fixtures a BATCHED implementation can replay (portfolio_random.npz is
+    a known-answer table, not a trace; hostcb_* traces need Python callables per env and are
+    replayed by the N=1 drop-in only)."""
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                  if not os.path.basename(p).startswith("portfolio_"))
+                  if not os.path.basename(p).startswith(("portfolio_", "hostcb_")))
 
 
 def load(name):

@@ -34,11 +34,17 @@ def _kwargs(g):
         # a CUSTOM python reward over the History, evaluated on the host by the drop-in
         k = rf[1]
         kw["reward_function"] = lambda h: k * np.log(h["portfolio_valuation", -1] / h["portfolio_valuation", -2])
+    elif isinstance(rf, list) and rf[0] == "custom":
+        import custom_callables
+        kw["reward_function"] = custom_callables.REWARD[rf[1]]
+        rf = None
     elif isinstance(rf, list):
         kw["reward_function"] = tuple(rf)
     if "dynamic_feature_functions" in cfg:
+        import custom_callables
         table = {"real_position": envs.dynamic_feature_real_position,
                  "last_position_taken": envs.dynamic_feature_last_position_taken}
+        table.update({"custom:" + k: v for k, v in custom_callables.DYNAMIC.items()})
         kw["dynamic_feature_functions"] = [table[n] for n in cfg["dynamic_feature_functions"]]
     return kw
 
@@ -89,7 +95,8 @@ def _replay_env(g, e, make_env, calls):
 
 SINGLE = ["c1_btc_default", "c1_btc_example", "c2_nowindow", "c3_window20", "drawdown_done",
           "no_autoreset", "persist_dynamic", "reward_scaled_onedyn", "reward_clipped_nodyn",
-          "limit_orders"]
+          "limit_orders",
+          "hostcb_custom_callables"]  # custom Python dynamic features + reward, run by the reference
 
 
 @pytest.mark.parametrize("name", SINGLE)
