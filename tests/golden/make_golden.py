@@ -203,6 +203,9 @@ def save(name, cfg, datasets, rec, note):
     out.update(rec)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
+    if "op" not in rec:  # not a trace (e.g. the metrics fixture)
+        print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+        return
     ends = int((rec["done"] | rec["truncated"]).sum())
     assert rec["op"].ndim == 2
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, calls={rec['op'].shape}, "
@@ -453,10 +456,42 @@ def custom_callables_trace():
          "History; same env object across episodes (in-place dynamic columns persist)")
 
 
+def metrics_fixture():
+    """hostcb_metrics.npz: what `get_metrics()` returns at the end of each episode of one
+    reference env (the two built-in percentage strings, environments.py:279-285, plus two
+    user metrics added with add_metric), for a fixed seed and action sequence."""
+    feat, close = random_walk(77, 400, 3, sigma=2e-2)
+    df = make_df(feat, close)
+    cfg = base_cfg(positions=[-1, 0, 1, 2], windows=3, trading_fees=1e-3,
+                   borrow_interest_rate=1e-4, max_episode_duration=60)
+    env = TradingEnv(df=df, **ref_kwargs(cfg))
+    env.add_metric("Position Changes", lambda h: int(np.sum(np.diff(h["position"]) != 0)))
+    env.add_metric("Episode Length", lambda h: len(h["position"]))
+    rng = np.random.default_rng(99)
+    actions = rng.integers(0, 4, (5, 80)).astype(np.int32)
+    results = []
+    for ep in range(5):
+        np.random.seed(900 + ep)
+        env.reset()
+        done = trunc = False
+        k = 0
+        while not (done or trunc):
+            _, _, done, trunc, _ = env.step(int(actions[ep, k]))
+            k += 1
+        results.append({str(a): (b if isinstance(b, str) else int(b))
+                        for a, b in env.get_metrics().items()})
+    save("hostcb_metrics", cfg, [(feat, close)],
+         {"actions": actions, "metrics_json": np.array(json.dumps(results))},
+         "get_metrics() of the reference after each of 5 episodes (np.random.seed(900 + ep) "
+         "before each reset, actions[ep, k] at step k)")
+
+
 if __name__ == "__main__":
     if "--only-custom" in sys.argv:
         custom_callables_trace()
+        metrics_fixture()
         sys.exit(0)
     main()
     portfolio_vectors()
     custom_callables_trace()
+    metrics_fixture()

@@ -464,3 +464,31 @@ def test_sb3_vecenv_adapter_against_single_envs():
     assert seen_term > 0 and seen_trunc > 0
     assert vec.env_is_wrapped(object) == [False] * N and vec.get_attr("num_envs", [0, 1]) == [N, N]
     vec.close()
+
+
+def test_get_metrics_equal_the_reference():
+    """tests/golden/hostcb_metrics.npz: the reference's get_metrics() after each of five
+    episodes (percentage strings formatted by environments.py:279-285 + two add_metric
+    callables); the drop-in must return the same dicts for the same seeds and actions."""
+    import json
+    from gym_trading_env_amd import TradingEnv
+    z = np.load(os.path.join(replay.GOLDEN_DIR, "hostcb_metrics.npz"), allow_pickle=False)
+    cfg = json.loads(str(z["cfg_json"]))
+    expected = json.loads(str(z["metrics_json"]))
+    df = make_df(z["feat_0"], z["close_0"])
+    env = TradingEnv(df=df, verbose=0, **{k: cfg[k] for k in (
+        "positions", "windows", "trading_fees", "borrow_interest_rate", "portfolio_initial_value",
+        "initial_position", "max_episode_duration")})
+    env.add_metric("Position Changes", lambda h: int(np.sum(np.diff(h["position"]) != 0)))
+    env.add_metric("Episode Length", lambda h: len(h["position"]))
+    for ep, want in enumerate(expected):
+        np.random.seed(900 + ep)
+        env.reset()
+        done = trunc = False
+        k = 0
+        while not (done or trunc):
+            _, _, done, trunc, _ = env.step(int(z["actions"][ep, k]))
+            k += 1
+        got = {str(a): (b if isinstance(b, str) else int(b)) for a, b in env.get_metrics().items()}
+        assert got == want, (ep, got, want)
+    env.close()
