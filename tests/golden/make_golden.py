@@ -486,12 +486,79 @@ def metrics_fixture():
          "before each reset, actions[ep, k] at step k)")
 
 
+HISTORY_ROWS = [
+    dict(idx=0, step=0, position=1, data={"close": 10.0, "open": 9.0},
+         portfolio_distribution={"asset": 1.0, "fiat": 0.0}, levels=[1, 2], reward=0),
+    dict(idx=1, step=1, position=0, data={"close": 11.0, "open": 10.0},
+         portfolio_distribution={"asset": 0.0, "fiat": 11.0}, levels=[3, 4], reward=0.5),
+    dict(idx=2, step=2, position=-1, data={"close": 12.5, "open": 11.0},
+         portfolio_distribution={"asset": -0.5, "fiat": 17.0}, levels=[5, 6], reward=-0.25),
+]
+HISTORY_EXPRESSIONS = [
+    "h.columns", "len(h)", "h.size", "h['idx'].tolist()", "h['data_close'].tolist()", "h[1]", "h[-1]",
+    "h['data_close', -1]", "h['position', 0]", "h['reward', 1]", "h['levels_1', -2]",
+    "h[['position', 'levels_1']].tolist()", "h[['idx']].shape", "h['data_open', 0:2].tolist()",
+    "h['step', -2:].tolist()", "str(h['idx'].dtype)", "h['nope']", "h['nope', 0]", "h[7]",
+    "h['idx', 7]", "h.add(idx=3, step=3)", "h.add(**dict(ROWS[0], extra=1))",
+]
+
+
+def _jsonable(v):
+    if isinstance(v, dict):
+        return {str(k): _jsonable(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_jsonable(x) for x in v]
+    if isinstance(v, (np.integer,)):
+        return int(v)
+    if isinstance(v, (np.floating,)):
+        return float(v)
+    return v
+
+
+def history_fixture():
+    """history_ops.json: what the reference's History (utils/history.py) answers to a list of
+    expressions (documented access patterns and a few misuse cases) after set() + two add()s,
+    and after a write through history[col, t] = v.  Exceptions are recorded by type name."""
+    from gym_trading_env.utils.history import History
+
+    def build():
+        h = History(max_size=10)
+        h.set(**HISTORY_ROWS[0])
+        for row in HISTORY_ROWS[1:]:
+            h.add(**row)
+        return h
+
+    out = {}
+    for expr in HISTORY_EXPRESSIONS:
+        h = build()
+        try:
+            out[expr] = {"value": _jsonable(eval(expr, {"h": h, "ROWS": HISTORY_ROWS}))}
+        except Exception as exc:  # noqa: BLE001
+            out[expr] = {"raises": type(exc).__name__}
+    h = build()
+    h["reward", -1] = 0.75
+    out["after h['reward', -1] = 0.75: h['reward'].tolist()"] = {"value": _jsonable(h["reward"].tolist())}
+    full = History(max_size=2)
+    full.set(a=1)
+    full.add(a=2)
+    try:
+        full.add(a=3)
+        out["add() beyond max_size"] = {"value": None}
+    except Exception as exc:  # noqa: BLE001
+        out["add() beyond max_size"] = {"raises": type(exc).__name__}
+    with open(os.path.join(HERE, "history_ops.json"), "w") as f:
+        json.dump({"rows": HISTORY_ROWS, "expressions": HISTORY_EXPRESSIONS, "answers": out}, f, indent=1)
+    print("history_ops.json:", len(out), "answers")
+
+
 if __name__ == "__main__":
     if "--only-custom" in sys.argv:
         custom_callables_trace()
         metrics_fixture()
+        history_fixture()
         sys.exit(0)
     main()
     portfolio_vectors()
     custom_callables_trace()
     metrics_fixture()
+    history_fixture()

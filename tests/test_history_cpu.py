@@ -55,3 +55,50 @@ def test_full_history_raises_like_the_reference():
     with pytest.raises(IndexError):  # history_storage[size] with size == height (history.py:36)
         h.add(a=2)
     assert len(h) == 2 and list(h["a"]) == [0, 1]
+
+
+def test_history_answers_like_the_reference():
+    """tests/golden/history_ops.json holds what the REFERENCE's History answered (values, or
+    the exception type) to a list of expressions; this History must answer the same."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "history_ops.json")
+    fx = json.load(open(path))
+    rows = fx["rows"]
+
+    def build():
+        h = History(max_size=10)
+        h.set(**rows[0])
+        for row in rows[1:]:
+            h.add(**row)
+        return h
+
+    def jsonable(v):
+        if isinstance(v, dict):
+            return {str(k): jsonable(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [jsonable(x) for x in v]
+        if isinstance(v, np.integer):
+            return int(v)
+        if isinstance(v, np.floating):
+            return float(v)
+        return v
+
+    for expr in fx["expressions"]:
+        want = fx["answers"][expr]
+        h = build()
+        try:
+            got = {"value": jsonable(eval(expr, {"h": h, "ROWS": rows}))}
+        except Exception as exc:  # noqa: BLE001
+            got = {"raises": type(exc).__name__}
+        assert got == want, (expr, got, want)
+    h = build()
+    h["reward", -1] = 0.75
+    assert jsonable(h["reward"].tolist()) == fx["answers"][
+        "after h['reward', -1] = 0.75: h['reward'].tolist()"]["value"]
+    full = History(max_size=2)
+    full.set(a=1)
+    full.add(a=2)
+    with pytest.raises(IndexError):
+        full.add(a=3)
+    assert fx["answers"]["add() beyond max_size"] == {"raises": "IndexError"}
