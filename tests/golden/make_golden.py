@@ -551,14 +551,41 @@ def history_fixture():
     print("history_ops.json:", len(out), "answers")
 
 
+def staging_fixture():
+    """set_df.npz: what TradingEnv._set_df (environments.py:128-143) derives from a DataFrame
+    with an awkward column set: which columns count as features (name CONTAINS 'feature'), which
+    go to the info array, and the staged arrays themselves."""
+    rng = np.random.default_rng(8)
+    T = 40
+    close = 100 * np.exp(np.cumsum(rng.normal(0, 1e-2, T)))
+    cols = ["volume", "feature_b", "open", "my_feature_a", "close", "Feature_caps", "high",
+            "refeatured", "low", "date_close"]
+    df = pd.DataFrame({c: rng.normal(0, 1, T) for c in cols},
+                      index=pd.date_range("2021-03-01", periods=T, freq="h"))
+    df["close"] = close
+    env = TradingEnv(df=df, positions=[0, 1], windows=None, verbose=0)
+    np.savez_compressed(
+        os.path.join(HERE, "set_df.npz"),
+        columns=np.array(cols), values=df[cols].to_numpy(np.float64),
+        features_columns=np.array(env._features_columns),
+        info_columns=np.array(env._info_columns),
+        nb_features=np.array(env._nb_features), nb_static_features=np.array(env._nb_static_features),
+        obs_array=np.asarray(env._obs_array, np.float32),
+        price_array=np.asarray(env._price_array, np.float64),
+        info_array=np.asarray(env._info_array, np.float64))
+    print("set_df.npz: features", env._features_columns, "info", env._info_columns)
+
+
 if __name__ == "__main__":
     if "--only-custom" in sys.argv:
         custom_callables_trace()
         metrics_fixture()
         history_fixture()
+        staging_fixture()
         sys.exit(0)
     main()
     portfolio_vectors()
     custom_callables_trace()
     metrics_fixture()
     history_fixture()
+    staging_fixture()

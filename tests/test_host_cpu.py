@@ -199,3 +199,22 @@ def test_integration_md_stub_matches_the_abi():
     assert C.sizeof(stub) == C.sizeof(_abi.GteConfig)
     for (name, a), (_, b) in zip(stub._fields_, _abi.GteConfig._fields_):
         assert C.sizeof(a) == C.sizeof(b), name
+
+
+def test_stage_dataframe_equals_the_reference_set_df():
+    """tests/golden/set_df.npz: what the reference's `_set_df` made of an awkward DataFrame
+    (feature columns = name contains 'feature', case-sensitive; the rest is info)."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "set_df.npz"), allow_pickle=False)
+    cols = [str(c) for c in z["columns"]]
+    df = pd.DataFrame(z["values"], columns=cols,
+                      index=pd.date_range("2021-03-01", periods=len(z["values"]), freq="h"))
+    s = staging.stage_dataframe(df, n_dyn=2)
+    assert s.feature_columns == [str(c) for c in z["features_columns"]]
+    assert s.n_obs == int(z["nb_features"]) and s.n_static == int(z["nb_static_features"])
+    np.testing.assert_array_equal(s.feat, z["obs_array"])
+    np.testing.assert_array_equal(s.close, z["price_array"])
+    ref_info = [str(c) for c in z["info_columns"]]  # a set difference: order is arbitrary there
+    assert sorted(s.info_columns) == sorted(ref_info)
+    for j, c in enumerate(ref_info):
+        np.testing.assert_array_equal(np.asarray(s.info_array[:, s.info_columns.index(c)], np.float64),
+                                      z["info_array"][:, j])
