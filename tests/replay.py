@@ -24,10 +24,10 @@ STATE_I32 = {"idx": "idx", "step": "step", "pos_index": "position_index",
 
 def golden_names():
     """Names of the trace fixtures a BATCHED implementation can replay (portfolio_random.npz is
-    a known-answer table, not a trace; hostcb_* traces need Python callables per env and are
-    replayed by the N=1 drop-in only)."""
+    a known-answer table and set_df.npz a staging fixture, not traces; hostcb_* traces need
+    Python callables per env and are replayed by the N=1 drop-in only)."""
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                  if not os.path.basename(p).startswith(("portfolio_", "hostcb_")))
+                  if not os.path.basename(p).startswith(("portfolio_", "hostcb_", "set_df")))
 
 
 def load(name):
