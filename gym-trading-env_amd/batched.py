@@ -206,6 +206,7 @@ class BatchedTradingEnv(_VectorEnvBase):
         self._state = _abi.GteStateView()
         self._epoch, self._state_epoch = 0, -1  # state snapshots are taken lazily
         self._snap_epoch, self._snap, self._snap_obs = -1, None, None  # numpy mode, per step
+        self._state_tensors = {}  # torch views of the state snapshot (state_tensor)
         self._torch = None
         self._t = {}
         if output == "torch":
@@ -310,6 +311,28 @@ class BatchedTradingEnv(_VectorEnvBase):
             _abi.check(self._lib, self._lib.gte_get_state(self._h, C.byref(self._state)))
             self._state_epoch = self._epoch
         return self._to_host(getattr(self._state, name), dt, self.num_envs)
+
+    def state_tensor(self, name: str):
+        """One per-env state array as a torch tensor ON THE DEVICE, without a copy: a view of the
+        library's struct-of-arrays snapshot (`gte_get_state`, refreshed once per step/reset on
+        first use).  For device-side reward shaping / extra observation features:
+        `envs.state_tensor("portfolio_valuation")`, `"real_position"`, `"idx"`, ...  The view is
+        overwritten by the snapshot taken after a later step."""
+        torch = self._torch
+        if torch is None:
+            raise ValueError("state_tensor needs output='torch'")
+        if self._state_epoch != self._epoch:
+            _abi.check(self._lib, self._lib.gte_get_state(self._h, C.byref(self._state)))
+            self._state_epoch = self._epoch
+        if name not in self._state_tensors:
+            dt = _abi.STATE_DTYPES[name]
+
+            class _Raw:  # the CUDA array interface torch.as_tensor understands (also on ROCm)
+                __cuda_array_interface__ = {
+                    "shape": (self.num_envs,), "typestr": "<i4" if dt == "int32" else "<f8",
+                    "data": (int(getattr(self._state, name)), False), "version": 2, "strides": None}
+            self._state_tensors[name] = torch.as_tensor(_Raw(), device=self._t["obs"].device)
+        return self._state_tensors[name]
 
     def read_output(self, name: str) -> np.ndarray:
         """Host copy of one output array of the last step/reset."""
