@@ -408,6 +408,27 @@ class BatchedTradingEnv(_VectorEnvBase):
             (h.set if k == start else h.add)(**row)
         return h
 
+    def save_for_render(self, env_id: int, dir="render_logs"):
+        """`TradingEnv.save_for_render` (environments.py:296-307) for one env of the batch: the
+        dataset's frame joined with the episode History rebuilt from the device trajectory log
+        (needs ``log_steps``), pickled as `<name>_<timestamp>.pkl` for the reference's renderer.
+        -> path of the file."""
+        import datetime
+        import os
+        import pandas as pd
+        h = self.history(env_id)
+        ds = self.datasets[int(self.state("dataset_index")[env_id])]
+        missing = [c for c in ("open", "high", "low", "close") if c not in (ds.info_columns or [])]
+        assert not missing, (
+            "Your DataFrame needs to contain columns : open, high, low, close to render !")
+        frame = pd.DataFrame(ds.info_array, columns=ds.info_columns, index=ds.index)
+        logged = pd.DataFrame({c: h[c] for c in h.columns}).set_index("date").sort_index()
+        os.makedirs(dir, exist_ok=True)
+        stamp = datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S")
+        path = os.path.join(dir, f"{ds.name}_env{int(env_id)}_{stamp}.pkl")
+        frame.join(logged, how="inner").to_pickle(path)
+        return path
+
     def episode_metrics(self, env_ids=None) -> dict:
         """Episode-end metrics of `calculate_metrics` (environments.py:279-286) for the envs
         whose episode just ended (default: `terminal_ids()`), from the device state:

@@ -280,6 +280,14 @@ def test_batched_history_and_custom_metrics_match_single_env(tmp_path):
     ref = single.get_metrics()
     assert m["Position Changes"][0] == ref["Position Changes"] and m["Episode Lenght"][4] == 30
     assert m["Market Return"][2] == ref["Market Return"]
+    # save_for_render: the same joined frame as the single env's (written by our own code just now)
+    single.save_for_render(dir=str(tmp_path / "one"))
+    path = batch.save_for_render(3, dir=str(tmp_path / "batch"))
+    a = pd.read_pickle(next((tmp_path / "one").glob("*.pkl")))
+    b = pd.read_pickle(path)
+    assert len(a) == len(b) == 30 and list(a.index) == list(b.index)
+    for col in ("open", "high", "low", "close", "portfolio_valuation", "position", "reward"):
+        np.testing.assert_allclose(np.asarray(a[col], float), np.asarray(b[col], float), rtol=1e-12)
     with pytest.raises(ValueError):
         BatchedTradingEnv(df, num_envs=2, output="numpy").add_metric("x", length)
     single.close(); batch.close()
