@@ -9,25 +9,49 @@ window 20 (obs 20x32 f32), positions [-1, 0, 1], fees 1e-4, borrow interest 3e-6
 (margin path live), random starts with max_episode_duration = 500, next-step
 auto-reset, uniform random actions pre-generated on the device.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the step kernel against the
-8 TB/s HBM peak with the ALGORITHMIC bytes of SURVEY §8d (5 250 B per env-step at
-this shape); `cpu_baseline` is the oracle's C restatement (oracle/, a "port")
-timed on this box's host cores on a bounded sample of the same workload.
+Episodes are DE-SYNCHRONISED before anything is timed (an untimed prologue resets
+env group e % 500 at prologue step e % 500), so every step of every window —
+the driver's 20-step one included — carries its share of episode ends and
+auto-resets (about N/500 per step) instead of a reset storm every 500 steps.
+
+Prints ONE JSON line (rank 0).  `roofline`:
+  achieved   ALGORITHMIC bytes of SURVEY §8d (5 250 B per env-step at this shape, no reuse
+             of the feature table credited) / kernel time — kept as the survey defines it;
+             with the table served from L2 it exceeds what the memory system really moves;
+  traffic    bytes per launch from the PMC counters (FETCH_SIZE x 1024 x 2 — the gfx950
+             half-count of wide reads — plus WRITE_SIZE x 1024), collected by THIS run in
+             separate `rocprofv3 --pmc` child passes of the same workload (falls back to
+             profiles/hbm_traffic.json, and says so, when rocprofv3 is unavailable);
+  frac       traffic / kernel time / 8 TB/s — the headline fraction, physical (<= 1);
+  frac_compulsory   the bytes no implementation can avoid (SURVEY §8d lower-bound
+             variant: obs store + one new table row + state + ring + returns = 2 970 B
+             per env-step) / kernel time / 8 TB/s;
+  regime     where the observation buffer lives: at 65 536 envs its 168 MB fit the 256 MiB
+             Infinity Cache (the counters then measure fabric traffic, not DRAM traffic);
+  hbm_regime the same kernel at 262 144 envs (671 MB of observations per launch, streamed
+             to HBM with non-temporal stores), with its own counters.
+`cpu_baseline` is the oracle's C restatement (oracle/, a "port") timed on this box's
+host cores on a bounded sample of the same workload.
 
 Multi-GPU (torchrun, one rank per GPU): envs shard with no data-path collective
 except the RCCL all-gather of the returns (reward, terminated, truncated: 6 bytes
-per env and step), which is what the north star names.  Every step's returns cross
-xGMI inside the timed region, a --gather-every (32) step block at a time on RCCL's
-stream while the following steps run (DESIGN.md §6 has the per-step alternatives
-measured); --gather-obs adds the observation all-gather (xGMI-bound, SURVEY §7
-hard part 7).  Weak scaling: 65 536 envs/GPU.
+per env and step), which is what the north star names.  `--gather-mode step` gathers
+synchronously after every step through the C ABI's own RCCL communicator
+(gte_allgather_returns); `--gather-mode block` (default) moves a --gather-every (32) step
+block at a time on RCCL's stream while the following steps run (DESIGN.md §6);
+--gather-obs adds the observation all-gather (xGMI-bound).  Weak scaling: 65 536 envs/GPU.
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -36,6 +60,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+INFINITY_CACHE_BYTES = 256 << 20
+HBM_REGIME_ENVS = 262_144  # 671 MB of observations per launch: far past the Infinity Cache
 
 WORKLOADS = {
     # BASELINE.json configs[2] (headline), [1] and the per-GPU share of [4]
@@ -59,8 +85,14 @@ def synthetic_dataset(dataset_id: int, T: int, n_static: int):
 
 
 def algorithmic_bytes(W: int, F_obs: int, F_s: int, n_dyn: int) -> int:
-    """SURVEY §8d B_alg per env-step."""
+    """SURVEY §8d B_alg per env-step (no reuse of the feature table credited)."""
     return 4 * W * F_obs + 4 * W * F_s + 8 + 104 + 4 * W * n_dyn + 4 * n_dyn + 4 + 6
+
+
+def compulsory_bytes(W: int, F_obs: int, F_s: int, n_dyn: int) -> int:
+    """SURVEY §8d lower-bound variant: perfect window reuse, i.e. the observation store, ONE
+    new table row, the price, the state record in and out, the dynamic ring and the returns."""
+    return 4 * W * F_obs + 4 * F_s + 8 + 104 + 4 * W * n_dyn + 4 * n_dyn + 4 + 6
 
 
 def env_kwargs(wl):
@@ -114,6 +146,136 @@ def cpu_baseline(wl, seconds_target: float = 12.0):
                       f"with OpenMP on {cores} threads, {el:.1f} s"}
 
 
+# ---------------------------------------------------------------------------------------
+# the workload, shared by the timed run, the HBM-regime leg and the PMC child passes
+
+def make_env(args, wl, N, rank, local_rank, return_slots=1):
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    D = wl["n_datasets"]
+    # configs 2-4: ONE dataset replicated on every rank; config 5: symbols partitioned by rank
+    data = [synthetic_dataset((rank * D + d) if D > 1 else 0, wl["T"], wl["n_static"])
+            for d in range(D)]
+    tuning = dict(envs_per_wave=args.epw, kernel_variant=args.variant,
+                  affinity_period=args.affinity)
+    if args.nt >= 0:
+        tuning["nontemporal_obs"] = args.nt
+    return BatchedTradingEnv(data if D > 1 else data[0], num_envs=N, seed=20240607,
+                             env_id_base=rank * N, device=local_rank, output="torch",
+                             return_slots=return_slots, **tuning, **env_kwargs(wl))
+
+
+def desynchronise(env, actions, cycle: int):
+    """Untimed prologue: spread the episode phases evenly.  A next-step auto-reset env repeats
+    every `cycle` = max_episode_duration step() calls (duration-1 steps + the reset call); group
+    g = env % cycle is reset (TradingEnv.reset on those envs, a masked gte_reset) right before
+    prologue step g, so afterwards about N/cycle envs end — and as many auto-reset — in EVERY
+    step.  Only reference-semantics calls are used."""
+    N = env.num_envs
+    group = np.arange(N) % cycle
+    n_rows = actions.shape[0]
+    for g in range(cycle):
+        if g:  # group 0 keeps the phase of the initial reset()
+            env.reset(mask=(group == g).astype(np.uint8))
+        env._launch_step(actions[g % n_rows])
+
+
+def run_steps(env, actions, first, count):
+    n_rows = actions.shape[0]
+    for i in range(first, first + count):
+        env.step(actions[i % n_rows])
+
+
+def pmc_traffic(args, N, timeout_s=150):
+    """Bytes per step-kernel launch from the hardware counters, collected NOW: one
+    `rocprofv3 --pmc <counter>` child pass per counter (FETCH_SIZE and WRITE_SIZE need
+    separate passes; no trace domain next to --pmc), each running `python3 bench.py
+    --pmc-child` = this very workload, de-synchronisation included.  -> dict or None."""
+    rocprof = shutil.which("rocprofv3")
+    if rocprof is None:
+        return None
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="gte_pmc_", dir="/tmp")
+        cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload,
+               "--envs", str(N), "--steps", "12", "--warmup", "4", "--epw", str(args.epw),
+               "--nt", str(args.nt), "--variant", str(args.variant), "--affinity", str(args.affinity)]
+        if args.sync_episodes:
+            cmd.append("--sync-episodes")
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            vals, name = [], None
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == counter and "gte_kernel<0" in r["Kernel_Name"]:
+                        vals.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+                        name = r["Kernel_Name"].split("(")[0].strip()
+            vals = [v for _, v in sorted(vals)][-12:]  # the post-warm-up launches
+            if not vals:
+                return None
+            out[counter] = sum(vals) / len(vals)
+            out["kernel"] = name
+        except Exception as e:  # noqa: BLE001 - any failure means "no live counters"
+            print(f"[bench] live PMC pass {counter} failed: {e!r}", file=sys.stderr)
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch = out["FETCH_SIZE"] * 1024 * 2  # KB -> B; gfx950 tallies 128-B read requests at 64 B
+    write = out["WRITE_SIZE"] * 1024
+    return {"bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
+            "kernel": out["kernel"],
+            "source": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this "
+                      "workload in this bench run (mean of the last 12 step-kernel dispatches; "
+                      "KB x1024, FETCH_SIZE x2 per MI355X_MICROARCH.md §HBM)"}
+
+
+def recorded_traffic(workload, N):
+    """Fallback: the counters committed under profiles/ for this workload and size."""
+    tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        rec = json.load(open(tp)).get(f"{workload}_{N}")
+        if rec:
+            return {"bytes_per_launch": rec["bytes_per_launch"], "fetch_bytes": rec["fetch_bytes"],
+                    "write_bytes": rec["write_bytes"], "kernel": rec.get("kernel"),
+                    "source": f"recorded: profiles/hbm_traffic.json[{workload}_{N}] "
+                              f"({rec.get('round', '?')}), not collected by this run"}
+    except Exception:
+        pass
+    return None
+
+
+def roofline_block(N, kernel_us, shape, traffic):
+    W, F_obs, F_s, n_dyn = shape
+    b_alg, b_min = algorithmic_bytes(*shape), compulsory_bytes(*shape)
+    secs = kernel_us * 1e-6
+    achieved = b_alg * N / secs / 1e9
+    obs_bytes = 4 * W * F_obs * N
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": None, "traffic": None,
+         "frac_algorithmic": achieved / HBM_PEAK_GBS,
+         "frac_compulsory": b_min * N / secs / 1e9 / HBM_PEAK_GBS,
+         "algorithmic_bytes_per_env_step": b_alg, "compulsory_bytes_per_env_step": b_min,
+         "kernel_us_per_launch": kernel_us,
+         "regime": ("infinity-cache: %.0f MB of observations per launch stay in the 256 MiB MALL "
+                    "(sc1 stores); counters = fabric traffic" % (obs_bytes / 1e6)
+                    if obs_bytes <= (190 << 20) else
+                    "hbm: %.0f MB of observations per launch stream to DRAM (non-temporal stores)"
+                    % (obs_bytes / 1e6))}
+    if traffic:
+        rate = traffic["bytes_per_launch"] / secs / 1e9
+        r.update(traffic=traffic["bytes_per_launch"], traffic_rate=rate,
+                 traffic_frac=rate / HBM_PEAK_GBS, frac=rate / HBM_PEAK_GBS,
+                 traffic_fetch_bytes=traffic["fetch_bytes"], traffic_write_bytes=traffic["write_bytes"],
+                 traffic_over_compulsory=traffic["bytes_per_launch"] / (b_min * N),
+                 traffic_source=traffic["source"], kernel=traffic.get("kernel"))
+    else:  # no counters: the compulsory-byte fraction is the only physical one available
+        r["frac"] = r["frac_compulsory"]
+        r["frac_is"] = "frac_compulsory (no PMC counters available)"
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,13 +289,27 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="kernel_variant bits (A/B timing)")
     ap.add_argument("--affinity", type=int, default=0,
                     help="L2-affinity re-sort period in steps (0 = default 128, -1 = off)")
+    ap.add_argument("--sync-episodes", action="store_true",
+                    help="skip the de-synchronising prologue: all envs start together, resets "
+                         "arrive as a storm every max_episode_duration steps (round-1 behaviour)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not spawn the rocprofv3 --pmc child passes (traffic then comes from "
+                         "profiles/hbm_traffic.json, or is null)")
+    ap.add_argument("--no-hbm-regime", action="store_true",
+                    help="skip the 262 144-env leg (observations streamed to HBM)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--gather-obs", action="store_true", help="also all-gather observations (N>1)")
+    ap.add_argument("--gather-mode", default="block", choices=["block", "step", "torch-step"],
+                    help="N>1: 'block' = asynchronous all-gather of --gather-every step blocks "
+                         "(torch.distributed); 'step' = synchronous per-step all-gather through "
+                         "libgte's own RCCL communicator (gte_allgather_returns); 'torch-step' = "
+                         "synchronous per-step through torch.distributed")
     ap.add_argument("--gather-every", type=int, default=32,
-                    help="N>1: all-gather the returns in blocks of this many steps (every step's "
-                         "reward/flags still cross xGMI inside the timed region; 1 = per step)")
+                    help="block mode: all-gather the returns in blocks of this many steps (every "
+                         "step's reward/flags still cross xGMI inside the timed region)")
     ap.add_argument("--gather-depth", type=int, default=2,
-                    help="N>1: blocks in rotation (>=2: a block's all-gather overlaps the steps "
-                         "that fill the next one on RCCL's stream; 1 = synchronous per-step gather)")
+                    help="block mode: blocks in rotation (a block's all-gather overlaps the steps "
+                         "that fill the next one on RCCL's stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a
@@ -142,12 +318,32 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    wl = WORKLOADS[args.workload]
+    N = args.envs or wl["envs"]
+    n_dyn = 2
+    W = wl["windows"] or 1
+    F_obs = wl["n_static"] + n_dyn
+    shape = (W, F_obs, wl["n_static"], n_dyn)
+    cycle = wl["max_episode_duration"]
+    hbm_leg = (world == 1 and not args.pmc_child and not args.no_hbm_regime
+               and args.workload == "c3" and N == wl["envs"])
+
+    # Counter passes first, while this process has not touched the GPU: each is a child
+    # `rocprofv3 --pmc X -- python3 bench.py --pmc-child ...` (the program itself after `--`).
+    live = {}
+    if world == 1 and not args.pmc_child and not args.no_pmc:
+        for n in [N] + ([HBM_REGIME_ENVS] if hbm_leg else []):
+            t = pmc_traffic(args, n)
+            if not t:
+                break  # rocprofv3 missing or failing: do not spend the time again
+            live[n] = t
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the env has no CPU fallback")
     # rehearsal knobs (a 1-GPU box can run 2 ranks on its one device over gloo; RCCL refuses
@@ -162,7 +358,7 @@ def main():
     if force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-    use_dist = world > 1 or force_dist
+    use_dist = (world > 1 or force_dist) and not args.pmc_child
     if use_dist:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)  # RCCL over xGMI
@@ -170,43 +366,39 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from gym_trading_env_amd.batched import BatchedTradingEnv
-    depth = max(1, args.gather_depth)
-    block = max(1, args.gather_every) if depth > 1 else 1
+    mode = args.gather_mode if use_dist else None
+    depth = max(2, args.gather_depth) if mode == "block" else 1
+    block = max(1, args.gather_every) if mode == "block" else 1
 
-    wl = WORKLOADS[args.workload]
-    N = args.envs or wl["envs"]
-    n_dyn = 2
-    W = wl["windows"] or 1
-    F_obs = wl["n_static"] + n_dyn
-    D = wl["n_datasets"]
-    # configs 2-4: ONE dataset replicated on every rank; config 5: symbols partitioned by rank
-    data = [synthetic_dataset((rank * D + d) if D > 1 else 0, wl["T"], wl["n_static"])
-            for d in range(D)]
-    tuning = dict(envs_per_wave=args.epw, kernel_variant=args.variant,
-                  affinity_period=args.affinity)
-    if args.nt >= 0:
-        tuning["nontemporal_obs"] = args.nt
-    env = BatchedTradingEnv(data if D > 1 else data[0], num_envs=N, seed=20240607,
-                            env_id_base=rank * N, device=local_rank, output="torch",
-                            return_slots=depth * block if use_dist else 1,
-                            **tuning, **env_kwargs(wl))
+    env = make_env(args, wl, N, rank, local_rank, return_slots=depth * block if use_dist else 1)
     gen = torch.Generator(device=dev)
     gen.manual_seed(99 + rank)
     n_rows = 64
     actions = torch.randint(0, 3, (n_rows, N), dtype=torch.int32, device=dev, generator=gen)
     env.reset()
+    if not args.sync_episodes:
+        desynchronise(env, actions, cycle)
+
+    if args.pmc_child:  # counted by rocprofv3 from outside: just run the launches
+        run_steps(env, actions, 0, args.warmup + args.steps)
+        env.synchronize()
+        env.close()
+        return
 
     # the return of a sharded run: RCCL all-gather of the packed (reward f32 | terminated u8 |
     # truncated u8) records, 6 bytes per env and step, which the kernel writes directly in
-    # that layout; by default a 32-step block at a time, overlapping the following steps
-    returns = pipe = None
+    # that layout
+    returns = pipe = comm = None
     if use_dist:
         from gym_trading_env_amd.distributed import ReturnGather, ReturnPipeline
-        returns = ReturnGather(N, dev, obs_shape=env.obs_shape if args.gather_obs else None,
-                               depth=depth, block=block)
-        if depth > 1:
-            pipe = ReturnPipeline(env, returns, block, depth)
+        if mode == "step" and backend == "nccl":
+            from gym_trading_env_amd.distributed import NativeReturnGather
+            comm = NativeReturnGather(env, with_obs=args.gather_obs)  # libgte's own communicator
+        else:
+            returns = ReturnGather(N, dev, obs_shape=env.obs_shape if args.gather_obs else None,
+                                   depth=depth, block=block)
+            if mode == "block":
+                pipe = ReturnPipeline(env, returns, block, depth)
 
     def drain():
         if pipe is not None:
@@ -215,17 +407,24 @@ def main():
     def one_step(i):
         if pipe is not None:
             pipe.before_step()  # rows about to be rewritten must have been gathered
-        obs, reward, term, trunc, _ = env.step(actions[i % n_rows])
+        env.step(actions[i % n_rows])
         if pipe is not None:
             pipe.after_step()   # starts the block's all-gather on block boundaries
+        elif comm is not None:
+            comm.gather()       # ncclAllGather on the env's stream, stream-ordered after the step
+            if args.gather_obs:
+                comm.gather_obs()
         elif returns is not None:
             returns.gather(env.packed_returns)
-        if returns is not None and args.gather_obs:
-            returns.gather_obs(obs)
+            if args.gather_obs:
+                returns.gather_obs(env._t["obs"])
+        if pipe is not None and args.gather_obs:
+            returns.gather_obs(env._t["obs"])
 
     for i in range(args.warmup):
         one_step(i)
     drain()
+    episodes0 = int(env.state("episode").sum())
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -247,46 +446,58 @@ def main():
         el, ev_ms = float(t[0]), float(t[1])
 
     # episodes really end inside the timed region (auto-reset is part of the step)
-    episodes = int(env.state("episode").sum()) - N  # beyond the initial reset
+    episodes = int(env.state("episode").sum()) - episodes0
     info = env.launch_info()
-    b_alg = algorithmic_bytes(W, F_obs, wl["n_static"], n_dyn)
     kernel_us = ev_ms * 1e3 / args.steps
-    achieved = b_alg * N / (kernel_us * 1e-6) / 1e9
-    traffic = None
-    tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tp) and N == wl["envs"]:  # the counters were collected at the default size
-        try:
-            traffic = json.load(open(tp)).get(f"{args.workload}_bytes_per_launch")
-        except Exception:
-            traffic = None
+    if comm is not None:
+        comm.close()
+    env.close()
+
+    hbm = None
+    if hbm_leg and rank == 0:
+        # the same kernel where the observations cannot stay on chip: 262 144 envs
+        big = make_env(args, wl, HBM_REGIME_ENVS, 0, local_rank)
+        acts = torch.randint(0, 3, (8, HBM_REGIME_ENVS), dtype=torch.int32, device=dev, generator=gen)
+        big.reset()
+        if not args.sync_episodes:
+            desynchronise(big, acts, cycle)
+        steps_b = max(20, min(args.steps, 200))
+        run_steps(big, acts, 0, 10)
+        big.timer_start()
+        run_steps(big, acts, 10, steps_b)
+        us_b = big.timer_stop() * 1e3 / steps_b
+        hbm = roofline_block(HBM_REGIME_ENVS, us_b, shape,
+                             live.get(HBM_REGIME_ENVS) or recorded_traffic(args.workload, HBM_REGIME_ENVS))
+        hbm.update(envs=HBM_REGIME_ENVS, steps=steps_b, env_steps_per_s=HBM_REGIME_ENVS / (us_b * 1e-6),
+                   launch=big.launch_info())
+        big.close()
+
     if rank == 0:
+        par = f"env-shard x{world}"
+        if use_dist:
+            par += " + RCCL all-gather(reward,flags" + (",obs)" if args.gather_obs else ")")
+            par += {"block": f" in {block}-step blocks overlapping the following steps (torch.distributed)",
+                    "step": ", synchronous per step, libgte's own RCCL communicator (C ABI)",
+                    "torch-step": ", synchronous per step (torch.distributed)"}[mode]
         out = {
             "metric": "env-steps/sec", "value": world * N * args.steps / el, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {N} envs/GPU x obs ({W},{F_obs}) f32, "
-                                   f"{D} dataset(s)/GPU of T={wl['T']}, positions [-1,0,1], fees 1e-4, borrow 3e-6, "
-                                   f"max_episode_duration {wl['max_episode_duration']}, next-step autoreset",
-                       "envs_per_gpu": N, "global_envs": world * N,
-                       "parallelism": f"env-shard x{world}" + (
-                           "" if world == 1 else " + RCCL all-gather(reward,flags"
-                           + (",obs)" if args.gather_obs else ")")
-                           + (f" in {block}-step blocks overlapping the following steps"
-                              if depth > 1 else ", synchronous per step")),
-                       "launch": info,
-                       "episodes_finished": episodes},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_env_step": b_alg,
-                         "kernel_us_per_launch": kernel_us},
+                                   f"{wl['n_datasets']} dataset(s)/GPU of T={wl['T']}, positions [-1,0,1], "
+                                   f"fees 1e-4, borrow 3e-6, max_episode_duration {cycle}, next-step autoreset",
+                       "envs_per_gpu": N, "global_envs": world * N, "parallelism": par,
+                       "episode_phase": ("synchronised (all envs reset together every %d steps)" % cycle
+                                         if args.sync_episodes else
+                                         "staggered by an untimed prologue: ~N/%d episode ends and "
+                                         "auto-resets in every step" % cycle),
+                       "launch": info, "episodes_finished": episodes},
+            "roofline": roofline_block(N, kernel_us, shape,
+                                       live.get(N) or recorded_traffic(args.workload, N)),
         }
-        if traffic:
-            # `achieved` prices ALGORITHMIC bytes (SURVEY §8d credits no reuse of the feature
-            # table between envs or steps), so with the table served from L2 it can pass the
-            # HBM peak; the counter-measured bytes per launch over the same kernel time:
-            out["roofline"]["traffic_rate"] = traffic / (kernel_us * 1e-6) / 1e9
-            out["roofline"]["traffic_frac"] = out["roofline"]["traffic_rate"] / HBM_PEAK_GBS
+        if hbm:
+            out["roofline"]["hbm_regime"] = hbm
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
             # the reference's OWN Python step() cannot run on this box (its files do not
@@ -318,7 +529,6 @@ def main():
                 except Exception:
                     pass
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    env.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -548,15 +548,12 @@ class BatchedTradingEnv(_VectorEnvBase):
     def _launch_step(self, actions):
         """The launch half of step(): nothing is copied back."""
         torch = self._torch
-        if torch is not None and isinstance(actions, torch.Tensor) and actions.is_cuda:
+        on_device = torch is not None and isinstance(actions, torch.Tensor) and actions.is_cuda
+        if on_device:
             if actions.dtype != torch.int32 or not actions.is_contiguous():
                 actions = actions.to(torch.int32).contiguous()
             if actions.shape != (self.num_envs,):
                 raise ValueError(f"expected {self.num_envs} actions")
-            self._keep = actions  # keep alive until the launch has consumed it
-            if self.return_slots > 1:
-                self._rotate_returns()
-            _abi.check(self._lib, self._lib.gte_step(self._h, C.c_void_p(actions.data_ptr()), 1))
         else:
             if torch is not None and isinstance(actions, torch.Tensor):
                 actions = actions.cpu().numpy()
@@ -567,6 +564,13 @@ class BatchedTradingEnv(_VectorEnvBase):
                 raise ValueError(f"expected {self.num_envs} actions")
             if a.size and (a.max() >= len(self.positions) or a.min() < -1):
                 raise IndexError("list index out of range")  # positions[position_index] (:234)
+        # whichever way the actions arrive, the step writes the NEXT row of the return buffers
+        if self.return_slots > 1:
+            self._rotate_returns()
+        if on_device:
+            self._keep = actions  # keep alive until the launch has consumed it
+            _abi.check(self._lib, self._lib.gte_step(self._h, C.c_void_p(actions.data_ptr()), 1))
+        else:
             _abi.check(self._lib, self._lib.gte_step(self._h, a.ctypes.data, 0))
         self._epoch += 1
 
@@ -660,8 +664,7 @@ class BatchedTradingEnv(_VectorEnvBase):
         flags, d["vector_bytes"] = divmod(d["vector_bytes"], 1000)
         d["phase_a"] = "cooperative" if flags & 1 else "per-wave"
         d["dyn_columns"] = ("global", "lds-raw-rings", "lds-resolved")[(flags >> 1) & 3]
-        d["structure"] = ("overlapped (waves 1-3 copy predicted windows during phase A)"
-                          if flags & 8 else "classic (phase A, barrier, gather)")
+        d["structure"] = "phase A, LDS barrier, gather"
         d["obs_stores"] = ("plain", "non-temporal", "sc1", "?")[(flags >> 4) & 3]
         d["resident_workgroups_per_cu"] = (flags >> 6) & 15
         return d

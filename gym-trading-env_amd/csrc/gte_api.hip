@@ -28,7 +28,6 @@ hipError_t launch_step_hot(const Params& p, int blocks, int threads, size_t smem
 hipError_t launch_step_hot_nt(const Params& p, int blocks, int threads, size_t smem, hipStream_t stream);
 int hot_blocks_per_cu(size_t smem);
 int hot_blocks_per_cu_nt(size_t smem);
-size_t lds_bytes_overlap(const Params& p);
 struct RolloutArgs {  // mirrors gte_rollout.hip
   const int32_t* actions; int32_t K; float* obs; float* reward; double* reward64;
   uint8_t* terminated; uint8_t* truncated; double* valuation;
@@ -36,7 +35,6 @@ struct RolloutArgs {  // mirrors gte_rollout.hip
 hipError_t launch_rollout(const Params& p, const RolloutArgs& r, int nt, int blocks, int threads,
                           hipStream_t stream);
 int rollout_blocks_per_cu(const Params& p, int nt);
-hipError_t launch_step_overlap(const Params& p, int vec, int nt, hipStream_t stream);
 struct StateSoA {
   int32_t *idx, *step, *pos, *dsi, *start, *episode, *needs_reset;
   double *asset, *fiat, *ia, *ifi, *pv, *realpos;
@@ -108,7 +106,6 @@ struct gte_env {
   int vec = 1, blocks = 0, threads = 256;
   bool coop = false;       // wave 0 of a workgroup runs phase A for the whole workgroup
   int stage = 0;           // dynamic columns: 0 global, 1 raw rings in LDS, 2 resolved in LDS
-  bool overlap = false;    // gte_step uses the overlapped kernel (gte_step_overlap_kernel)
   int32_t* term_base = nullptr;  // the two-slot terminal counter in use (owned or bound)
   int term_slot = 0;       // slot the last launch added to
   // L2-affinity processing order (gte_kernels.hip, "L2-affinity permutation")
@@ -161,6 +158,8 @@ static int validate(const gte_config* c) {
     if (c->dyn_kind[i] != GTE_DYN_LAST_POSITION && c->dyn_kind[i] != GTE_DYN_REAL_POSITION)
       return fail(GTE_ERR_INVALID, "dyn_kind[%d] = %d unknown", i, c->dyn_kind[i]);
   if (c->window < 0) return fail(GTE_ERR_INVALID, "window must be >= 0");
+  if (c->window >= 32768)  // JobRec.meta keeps the zero-row count of a window in 15 bits
+    return fail(GTE_ERR_INVALID, "window must be < 32768");
   const int64_t W = c->window > 0 ? c->window : 1;
   if (W * (c->n_static + c->n_dyn) > (1 << 18))
     return fail(GTE_ERR_INVALID, "window * F_obs > 2^18 floats unsupported");
@@ -338,7 +337,7 @@ int gte_create(const gte_config* cfg, gte_env** out) {
     // Cost model: rounds x (fixed part of a workgroup + its copy work).
     const bool hot_shape = E->vec == 4 && vpe >= 64 && p.nd > 0 && !p.persist && !cfg->final_obs &&
                            (E->cfg.nontemporal_obs == 1 || E->cfg.nontemporal_obs == 2) &&
-                           !(cfg->kernel_variant & (1 | 2 | 4));
+                           !(cfg->kernel_variant & (1 | 2));
     if (hot_shape) {
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
@@ -375,19 +374,6 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   const int64_t waves = ((int64_t)p.N + epw - 1) / epw;
   E->threads = 256;
   E->blocks = (int)((waves + 3) / 4);
-  // overlapped step kernel (opt-in, kernel_variant bit 4): windowed, W-deep rings, 64 envs per
-  // workgroup.  Across builds it measured 43-46 us against 42-47 us for the classic kernel
-  // (co-compiled templates perturb each other's code generation), while classic + sc1 stores
-  // was 42.7 us in every build, so that is the default.  gte_reset always uses the classic
-  // kernel (a reset has no prediction to start from).
-  if ((cfg->kernel_variant & 4) && !cfg->final_obs && !p.persist && p.W >= 2 && E->stage == 1 &&
-      (cfg->envs_per_wave == 0 || cfg->envs_per_wave == 16) && gte::lds_bytes_overlap(p) <= 48 * 1024) {
-    E->overlap = true;
-    epw = 16;
-    p.epw = 16;
-    E->coop = true;
-    E->blocks = (p.N + 63) / 64;
-  }
   // L2-affinity order: only worth it when every XCD gets several workgroups and the
   // windows are big enough to be bandwidth-bound
   {
@@ -440,22 +426,45 @@ int gte_upload_dataset(gte_env* E, int32_t d, const float* feat, const double* c
                 (long long)T, p.max_dur);
   if (E->finalized && p.persist && T > p.depth)
     return fail(GTE_ERR_STATE, "dyn_persist: cannot upload a longer dataset after the first reset");
+  // After a reset envs may sit anywhere in the old table: a shorter replacement would leave
+  // their next step reading rows past the new allocation.  (The reference's own _set_df is only
+  // ever followed by reset(); MultiDatasetTradingEnv's drop-in builds a fresh batch per dataset.)
+  if (E->was_reset && T < E->h_ds[d].T)
+    return fail(GTE_ERR_STATE, "dataset %d: cannot replace %lld rows by %lld after gte_reset "
+                "(running environments may be past the new end); create a new env instead",
+                d, (long long)E->h_ds[d].T, (long long)T);
   HIPCHK(hipSetDevice(E->cfg.device));
   HIPCHK(hipStreamSynchronize(E->stream));
   const void* srcs[4] = {feat, close, high, low};
   const size_t bytes[4] = {sizeof(float) * (size_t)T * p.Fobs, sizeof(double) * (size_t)T,
                            sizeof(double) * (size_t)T, sizeof(double) * (size_t)T};
+  // new buffers first; the old ones stay in the descriptor table (and valid) until the new
+  // table has been published, so a failure on the way leaves the env exactly as it was
   void* dev[4] = {nullptr, nullptr, nullptr, nullptr};
+  auto undo = [&]() { for (void* q : dev) if (q) (void)hipFree(q); };
   for (int k = 0; k < 4; ++k) {
-    if (E->ds_allocs[k][d]) { (void)hipFree(E->ds_allocs[k][d]); E->ds_allocs[k][d] = nullptr; }
     if (!srcs[k]) continue;
-    HIPCHK(hipMalloc(&dev[k], bytes[k]));
-    E->ds_allocs[k][d] = dev[k];
-    HIPCHK(hipMemcpy(dev[k], srcs[k], bytes[k], hipMemcpyHostToDevice));
+    hipError_t e = hipMalloc(&dev[k], bytes[k]);
+    if (e == hipSuccess) e = hipMemcpy(dev[k], srcs[k], bytes[k], hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      undo();
+      return fail(e == hipErrorOutOfMemory ? GTE_ERR_OOM : GTE_ERR_HIP, "uploading dataset %d: %s", d,
+                  hipGetErrorString(e));
+    }
   }
+  const DatasetDesc before = E->h_ds[d];
   E->h_ds[d] = DatasetDesc{(const float*)dev[0], (const double*)dev[1], (const double*)dev[2],
                            (const double*)dev[3], T};
-  HIPCHK(hipMemcpy(E->d_ds, E->h_ds.data(), sizeof(DatasetDesc) * p.D, hipMemcpyHostToDevice));
+  const hipError_t e = hipMemcpy(E->d_ds, E->h_ds.data(), sizeof(DatasetDesc) * p.D, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    E->h_ds[d] = before;
+    undo();
+    return fail(GTE_ERR_HIP, "publishing the descriptor of dataset %d: %s", d, hipGetErrorString(e));
+  }
+  for (int k = 0; k < 4; ++k) {
+    if (E->ds_allocs[k][d]) (void)hipFree(E->ds_allocs[k][d]);
+    E->ds_allocs[k][d] = dev[k];
+  }
   return GTE_OK;
 }
 
@@ -559,14 +568,16 @@ int gte_set_autoreset_injection(gte_env* E, int32_t n, const int32_t* inj_idx,
   HIPCHK(hipStreamSynchronize(E->stream));
   Params& p = E->p;
   const size_t count = (size_t)p.N * (size_t)n;
+  // the queues of an earlier call are released here (the stream is idle: nothing reads them)
   auto put = [&](int32_t** slot, const int32_t* src, const int32_t** param) -> int {
     *param = nullptr;
+    if (*slot) { (void)hipFree(*slot); *slot = nullptr; }
     if (!src || n == 0) return GTE_OK;
-    int32_t* dev = nullptr;
-    TRY(dev_alloc(E, &dev, count, false));  // released in gte_destroy
+    void* dev = nullptr;
+    HIPCHK(hipMalloc(&dev, sizeof(int32_t) * count));
+    *slot = (int32_t*)dev;  // owned by the env from here on (freed above or in gte_destroy)
     HIPCHK(hipMemcpy(dev, src, sizeof(int32_t) * count, hipMemcpyHostToDevice));
-    *slot = dev;
-    *param = dev;
+    *param = *slot;
     return GTE_OK;
   };
   TRY(put(&E->d_q_idx, inj_idx, &p.q_idx));
@@ -602,9 +613,7 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
   E->term_slot ^= 1;
   p.term_count = E->term_base + E->term_slot;
   p.term_count_next = E->term_base + (E->term_slot ^ 1);
-  if (E->overlap)
-    HIPCHK(gte::launch_step_overlap(p, E->vec, E->cfg.nontemporal_obs, E->stream));
-  else if (E->vec == 4 && E->cfg.nontemporal_obs == 2 && E->coop && E->stage == 1 &&
+  if (E->vec == 4 && E->cfg.nontemporal_obs == 2 && E->coop && E->stage == 1 &&
            !(E->cfg.kernel_variant & 64))
     HIPCHK(gte::launch_step_hot(p, E->blocks, E->threads, gte::lds_bytes(p, E->stage), E->stream));
   else if (E->vec == 4 && E->cfg.nontemporal_obs == 1 && E->coop && E->stage == 1 &&
@@ -631,7 +640,7 @@ int gte_rollout(gte_env* E, const int32_t* actions, int32_t n_steps, const gte_r
   if (b->obs && ((uintptr_t)b->obs & 15)) return fail(GTE_ERR_INVALID, "obs must be 16-byte aligned");
   HIPCHK(hipSetDevice(E->cfg.device));
   // kernel_variant 128 = never fused (A/B and tests of the per-launch path)
-  const bool fused = E->vec == 4 && E->coop && E->stage == 1 && !E->overlap && !E->cfg.final_obs &&
+  const bool fused = E->vec == 4 && E->coop && E->stage == 1 && !E->cfg.final_obs &&
                      E->cfg.log_steps == 0 && !(E->cfg.kernel_variant & 128);
   // per-step observation rows are written once and not read back by the kernels: a stream
   struct RestoreStorePolicy {  // whatever path leaves this function, the env's policy returns
@@ -955,7 +964,7 @@ int gte_get_launch_info(gte_env* E, int32_t* envs_per_wave, int32_t* threads_per
   if (threads_per_block) *threads_per_block = E->threads;
   if (n_blocks) *n_blocks = E->blocks;
   if (vector_bytes)
-    *vector_bytes = E->vec * 4 + 1000 * ((E->coop ? 1 : 0) + 2 * E->stage + (E->overlap ? 8 : 0) +
+    *vector_bytes = E->vec * 4 + 1000 * ((E->coop ? 1 : 0) + 2 * E->stage +
                                          16 * E->cfg.nontemporal_obs + 64 * (E->hot_per_cu & 15));
   return GTE_OK;
 }
@@ -978,6 +987,8 @@ void gte_destroy(gte_env* E) {
   for (auto& v : E->ds_allocs)
     for (void* ptr : v)
       if (ptr) (void)hipFree(ptr);
+  for (int32_t* q : {E->d_q_idx, E->d_q_pos, E->d_q_ds})
+    if (q) (void)hipFree(q);
   if (E->h_snap) (void)hipHostFree(E->h_snap);
   if (E->ev0) (void)hipEventDestroy(E->ev0);
   if (E->ev1) (void)hipEventDestroy(E->ev1);

@@ -18,11 +18,11 @@
 //            in flight with the dynamic columns, which the wave first stages in
 //            LDS with one coalesced pass over its envs' small dynamic stores.
 //
-// Kernels:  gte_step_overlap_kernel  step, windowed shapes (default): waves 1-3
-//                                    gather predicted windows WHILE wave 0 runs
-//                                    phase A for the 64 envs;
-//           gte_kernel<MODE,...>     classic order (phase A, barrier, gather):
-//                                    resets, dyn_persist, windows=None, odd shapes;
+// Kernels:  gte_kernel<MODE,...>     phase A, LDS barrier, gather: every step and reset
+//                                    (the headline instantiation is compiled alone in
+//                                    gte_hot.hip / gte_hot_nt.hip);
+//           gte_rollout_kernel       K steps in one launch, windows resident in LDS
+//                                    (gte_rollout.hip);
 //           gte_affinity_*           counting sort of the envs by table region
 //                                    (processing order, speed only);
 //           gte_add_orders / gte_extract_state / gte_rewind_queue: small helpers.
@@ -239,46 +239,15 @@ __device__ inline void make_job(const Params& p, int e, const EnvRegs& s, bool f
   job.flags = 1 | ((fresh && p.persist) ? 2 : 0);
 }
 
-// The window a step will most likely produce, known from the OLD state alone (before
-// the fp64 state machine has run): the env advances one row (or stays, if it is a
-// frozen finished env).  Envs that are about to be reset have no prediction.  Used by
-// the overlapped step kernel.  Non-persist layout only (W-deep ring).
-struct Prediction {
-  const float* src;
-  int32_t slot0, n_zero;
-  bool ok;
-};
-
-__device__ inline Prediction predict_job(const Params& p, int32_t idx, int32_t dsi,
-                                         int32_t start, int32_t needs_reset) {
-  Prediction q;
-  q.ok = true;
-  int32_t idx_new = idx + 1;
-  if (needs_reset) {
-    if (p.autoreset == GTE_AUTORESET_NEXT_STEP) q.ok = false;   // will be reset
-    else if (idx >= (int32_t)p.ds[dsi].T - 1) idx_new = idx;   // frozen
-  }
-  const int32_t first = idx_new - p.W + 1;
-  q.src = p.ds[dsi].feat + (int64_t)first * p.Fobs;
-  q.slot0 = (idx_new + 1) % p.W;
-  const int32_t nz = start - first;
-  q.n_zero = nz < 0 ? 0 : (nz > p.W - 1 ? p.W - 1 : nz);
-  return q;
-}
-
 // ---------------------------------------------------------------------------
 // phase A
-
-struct OldState {  // what phase A started from (for the prediction check)
-  int32_t idx, dsi, start, needs_reset;
-};
 
 // compact: add the envs whose episode ended to the terminal list (off for the inner steps
 // of a fused rollout, which keeps per-step flags instead); pv_out: the valuation after the step.
 template <int MODE>
 __device__ inline void phase_a(const Params& p, int e, bool active, int lane, ObsJob& job,
-                               OldState* old = nullptr, FinalJob* fin = nullptr,
-                               bool compact = true, double* pv_out = nullptr) {
+                               FinalJob* fin = nullptr, bool compact = true,
+                               double* pv_out = nullptr) {
   if (fin) fin->flags = 0;
   job.src = nullptr; job.slot0 = 0; job.n_zero = 0; job.idx = 0; job.flags = 0;
 #pragma unroll
@@ -307,7 +276,6 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
   if (active) {
     EnvRegs s;
     load_state(p, e, s);
-    if (old) { old->idx = s.idx; old->dsi = s.dsi; old->start = s.start; old->needs_reset = s.needs_reset; }
     int32_t action = p.actions[e];
     GTE_STAMP(2);  // record + action arrived
     // positions[position_index] raises IndexError in the reference (:234); a device-side
@@ -473,7 +441,8 @@ struct alignas(16) JobRec {
   uint64_t src;   // first row of the window in the feature table
   int32_t env;    // env id processed in this slot (perm[slot], or the slot itself); -1 = none
   uint32_t meta;  // bit0 copy the window, bit1 zero the env's dynamic store,
-                  // bits 2..16 n_zero, bits 17..31 slot0  (W < 32768)
+                  // bits 2..16 n_zero (W < 32768, gte_create checks), bits 17..31 slot0 of the
+                  // W-deep ring (meaningless with dyn_persist: dyn_value uses the row itself)
 };
 __device__ inline uint32_t pack_meta(int flags, int n_zero, int slot0) {
   return (uint32_t)(flags & 3) | ((uint32_t)n_zero << 2) | ((uint32_t)slot0 << 17);
@@ -519,8 +488,15 @@ __device__ inline float dyn_value(const Params& p, const WgLds& L, int s, const 
   if (w == p.W - 1) return L.cur[s * GTE_MAX_DYN + i];  // current row: from phase A
   const uint32_t m = L.job[s].meta;
   if (w < meta_n_zero(m)) return 0.0f;                   // never written: reads as zero
-  int32_t slot = meta_slot0(m) + w;
-  if (!p.persist && slot >= p.W) slot -= p.W;
+  int32_t slot;
+  if (p.persist) {
+    // T-deep column: the slot IS the table row, which does not fit JobRec.meta's 15 bits
+    // (rows >= 32768 used to alias): take it from the current row published next to the job
+    slot = L.idx[s] - p.W + 1 + w;
+  } else {
+    slot = meta_slot0(m) + w;
+    if (slot >= p.W) slot -= p.W;
+  }
   return ring_e[(int64_t)slot * p.nd + i];
 }
 
@@ -772,7 +748,7 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
     const int e = active ? (p.perm ? p.perm[wg_first + s] : wg_first + s) : 0;
     ObsJob job;
     FinalJob fin;
-    phase_a<MODE>(p, e, active, lane, job, nullptr, p.final_obs ? &fin : nullptr);
+    phase_a<MODE>(p, e, active, lane, job, p.final_obs ? &fin : nullptr);
     if (owns) publish_job(L, s, job);  // slots past the last env get flags = 0
     if (owns && p.final_obs) L.fin[s] = fin;
   }
@@ -799,223 +775,6 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
 }
 
 #ifndef GTE_HOT_ONLY
-// ---------------------------------------------------------------------------
-// Overlapped step kernel (default for windowed, non-persist shapes).
-//
-// Phase A is a ~10 us latency chain (record gather, price gathers, fp64 divisions)
-// during which the classic kernel moves no observation bytes.  Almost all of a window
-// does not depend on it: a stepping env advances one row, so rows 0..W-2 of its new
-// window (static columns AND the dynamic values of earlier rows, which sit in the
-// env's ring) are known from the OLD state.  Workgroup = 4 waves = 64 envs:
-//   waves 1..3  predict the windows of their 16 envs from the old state and copy
-//               rows 0..W-2 immediately;
-//   wave 0      runs phase A for all 64 envs (one per lane), publishes the real jobs
-//               and lists the envs whose whole window must (still) be copied: its own
-//               16 envs and every env whose real job differs from the prediction
-//               (resets);
-//   barrier, then all 4 waves share (A) the listed envs' whole windows and (B) the
-//               last row of every other env (it needs phase A's dynamic values).
-// A mispredicted env's early rows are simply rewritten in (A); __syncthreads drains
-// every wave's stores first.
-struct OverlapLds {
-  JobRec* job;      // [64] real jobs (wave 0)
-  JobRec* pjob;     // [64] predicted jobs (waves 1..3, slots 16..63)
-  float* cur;       // [64][GTE_MAX_DYN]
-  int32_t* full;    // [64] 1 = whole window copied after the barrier
-  int32_t* list;    // [64] compacted slots with full == 1
-  int32_t* n_full;  // [1]
-  float* staged;    // [64][W][nd] raw rings
-};
-
-__device__ inline OverlapLds carve_overlap(unsigned char* base) {
-  OverlapLds L;
-  L.job = (JobRec*)base;   base += 16 * 64;
-  L.pjob = (JobRec*)base;  base += 16 * 64;
-  L.cur = (float*)base;    base += 4 * GTE_MAX_DYN * 64;
-  L.full = (int32_t*)base; base += 4 * 64;
-  L.list = (int32_t*)base; base += 4 * 64;
-  L.n_full = (int32_t*)base; base += 16;
-  L.staged = (float*)base;
-  return L;
-}
-
-size_t lds_bytes_overlap(const Params& p) {
-  return 64 * (16 + 16 + 4 * GTE_MAX_DYN + 4 + 4) + 16 + (size_t)64 * p.W * (p.nd ? p.nd : 1) * 4;
-}
-
-// One flat gather over `n_items` envs x `per_env` vectors (vectors vec0 .. vec0+per_env-1
-// of each window).  Item el is LDS slot list[el] (or s_base + el).  The calling wave
-// takes chunks k_begin, k_begin + k_stride, ... of 64*U vectors.
-//   EARLY: jobs are predictions and only rows < W-1 are touched, so the dynamic values
-//          come from the staged ring (or are zero); otherwise the row may be the current
-//          one, whose values are in L.cur.
-template <int VEC, int NT, int U, bool EARLY>
-__device__ inline void copy_flat(const Params& p, const OverlapLds& L, const JobRec* jobs,
-                                 const int32_t* list, int s_base, const int32_t* skip_if,
-                                 uint32_t n_items, uint32_t per_env, uint64_t per_env_magic,
-                                 uint32_t vec0, uint32_t k_begin, uint32_t k_stride, int lane,
-                                 uint64_t fv_magic) {
-  typedef float vec_t __attribute__((ext_vector_type(VEC)));
-  const uint32_t V = (uint32_t)(p.W * p.Fobs);
-  const uint32_t FV = (uint32_t)p.Fobs / VEC;
-  const uint32_t total = n_items * per_env;
-  for (uint32_t k0 = k_begin; k0 < total; k0 += k_stride) {
-    vec_t v[U];
-    uint32_t jj[U], mm[U];
-    int32_t env[U], ss[U];
-    bool ok[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t k = k0 + (uint32_t)u * 64u + (uint32_t)lane;
-      const bool in = k < total;
-      const uint32_t kk = in ? k : 0u;
-      const uint32_t el = fastdiv40(kk, per_env_magic);
-      jj[u] = vec0 + (kk - el * per_env);
-      const int s = list ? list[el] : s_base + (int)el;
-      const JobRec j = jobs[s];  // one ds_read_b128
-      ss[u] = s;
-      mm[u] = j.meta;
-      env[u] = j.env;
-      ok[u] = in && (j.meta & 1u) && !(skip_if && skip_if[s]);
-      if (ok[u]) { if (p.debug & 8) v[u] = (vec_t)(float)jj[u]; else v[u] = load_global<vec_t>(j.src, (int64_t)jj[u]); }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (!ok[u]) continue;
-      const uint32_t w = fastdiv40(jj[u], fv_magic);
-      const int col = (int)(jj[u] - w * FV) * VEC;
-      if (col + VEC > p.Fs && !(p.debug & 2)) {  // this vector holds dynamic columns
-        const int s = ss[u];
-        const bool is_cur = !EARLY && ((int)w == p.W - 1);
-        int32_t slot = meta_slot0(mm[u]) + (int32_t)w;
-        slot -= (slot >= p.W) ? p.W : 0;
-        const bool zero = !is_cur && (int)w < meta_n_zero(mm[u]);
-        const float* a = is_cur ? &L.cur[s * GTE_MAX_DYN] : &L.staged[(s * p.W + slot) * p.nd];
-        float x[GTE_MAX_DYN];
-#pragma unroll
-        for (int i = 0; i < GTE_MAX_DYN; ++i) x[i] = (i < p.nd && !zero) ? a[i] : 0.0f;
-        if constexpr (VEC == 4) {
-          set_tail(v[u], p.nd, x);  // col + 4 > Fs  <=>  the row's last vector
-        } else {
-          const int i = col - p.Fs;
-          float r = x[0];
-#pragma unroll
-          for (int kq = 1; kq < GTE_MAX_DYN; ++kq) r = (i == kq) ? x[kq] : r;
-          v[u] = r;
-        }
-      }
-      store_out<NT>((vec_t*)(p.obs + (int64_t)env[u] * V + (int64_t)jj[u] * VEC), v[u]);
-    }
-  }
-}
-
-template <int VEC, int NT, int U>
-__global__ __launch_bounds__(256) void gte_step_overlap_kernel(const Params p, const uint64_t fv_magic,
-                                                               const uint64_t wnd_magic,
-                                                               const uint64_t early_magic,
-                                                               const uint64_t vpe_magic) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char gte_smem[];
-  const int lane = threadIdx.x & 63;
-  const int wib = threadIdx.x >> 6;
-  if (blockIdx.x == 0 && threadIdx.x == 0) p.term_count_next[0] = 0;
-  const int wg_first = blockIdx.x * 64;
-  const int n_wg = min(64, p.N - wg_first);  // grid = ceil(N / 64)
-  const OverlapLds L = carve_overlap(gte_smem);
-  const uint32_t FV = (uint32_t)p.Fobs / VEC;
-  const uint32_t VPE = (uint32_t)(p.W * p.Fobs) / VEC;
-  // 16 slots per wave.  Wave 0's envs can only be copied after phase A; giving it fewer
-  // (8 / 4 / 1 of the 64) measured no better (46.8 / 46.9 / 48.2 us vs 46.3 us) and a
-  // run-time split cost 3 us against this compile-time one (profiles/r01_tune_overlap.log)
-  const int s_first = wib * 16;
-  const int n_env = max(0, min(16, n_wg - s_first));
-
-  // env ids of this wave's slots (identity or the L2-affinity permutation), raw rings
-  if (lane < 16) {
-    const int slot = wg_first + s_first + lane;
-    const int env = (lane < n_env) ? (p.perm ? p.perm[slot] : slot) : -1;
-    L.job[s_first + lane].env = env;
-    L.pjob[s_first + lane].env = env;
-    L.pjob[s_first + lane].meta = 0;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (p.nd > 0 && n_env > 0) {
-    const uint32_t WND = (uint32_t)(p.W * p.nd);
-    const uint32_t total = (uint32_t)n_env * WND;
-    float* dst = L.staged + (uint32_t)s_first * WND;
-    for (uint32_t k = (uint32_t)lane; k < total; k += 64u) {
-      const uint32_t el = fastdiv40(k, wnd_magic);
-      dst[k] = p.ring[(int64_t)L.job[s_first + (int)el].env * WND + (k - el * WND)];
-    }
-  }
-
-  if (wib == 0) {
-    // ---------------- wave 0: phase A for the whole workgroup
-    const int s = lane;
-    const bool active = s < n_wg;
-    const int e = active ? (p.perm ? p.perm[wg_first + s] : wg_first + s) : 0;
-    ObsJob job;
-    OldState old = {0, 0, 0, 0};
-    phase_a<MODE_STEP>(p, e, active, lane, job, &old);
-    L.job[s].src = (uint64_t)job.src;
-    L.job[s].meta = pack_meta(job.flags, job.n_zero, job.slot0);
-#pragma unroll
-    for (int i = 0; i < GTE_MAX_DYN; ++i) L.cur[s * GTE_MAX_DYN + i] = job.cur[i];
-    bool full = false;
-    if (active && (job.flags & 1)) {
-      const Prediction q = predict_job(p, old.idx, old.dsi, old.start, old.needs_reset);
-      full = s < 16 || !q.ok || q.src != job.src || q.slot0 != job.slot0 || q.n_zero != job.n_zero;
-    }
-    L.full[s] = full ? 1 : 0;
-    const unsigned long long m = __ballot(full);
-    if (full) L.list[__popcll(m & ((1ull << lane) - 1ull))] = s;
-    if (lane == 0) L.n_full[0] = __popcll(m);
-  } else if (n_env > 0 && !(p.debug & 1)) {
-    // ---------------- waves 1..3: rows 0..W-2 of the predicted windows, right away
-    if (lane < n_env) {
-      const EnvRec* r = &p.rec[L.job[s_first + lane].env];
-      const Prediction q = predict_job(p, r->idx, r->dsi, r->start, r->needs_reset);
-      L.pjob[s_first + lane].src = (uint64_t)q.src;
-      L.pjob[s_first + lane].meta = pack_meta(q.ok ? 1 : 0, q.n_zero, q.slot0);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    copy_flat<VEC, NT, U, true>(p, L, L.pjob, nullptr, s_first, nullptr, (uint32_t)n_env,
-                                VPE - FV, early_magic, 0u, 0u, 64u * U, lane, fv_magic);
-  }
-  // every wave's early stores must have completed before any rewrite below; the sc1
-  // stores are inline asm the compiler does not count, so wait explicitly
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (p.debug & 1) return;
-  // (A) whole windows of the listed envs, (B) last rows of all the others; 4 waves interleave
-  copy_flat<VEC, NT, U, false>(p, L, L.job, L.list, 0, nullptr, (uint32_t)L.n_full[0], VPE, vpe_magic,
-                               0u, (uint32_t)wib * 64u * U, 4u * 64u * U, lane, fv_magic);
-  copy_flat<VEC, NT, U, false>(p, L, L.job, nullptr, 0, L.full, (uint32_t)n_wg, FV, fv_magic, VPE - FV,
-                               (uint32_t)wib * 64u * U, 4u * 64u * U, lane, fv_magic);
-}
-
-hipError_t launch_step_overlap(const Params& p, int vec, int nt, hipStream_t stream) {
-  const uint32_t V = (uint32_t)(p.W * p.Fobs);
-  const uint32_t FV = (uint32_t)p.Fobs / vec, VPE = V / vec;
-  auto magic = [](uint32_t d) { return ((1ull << 40) + d - 1) / (d ? d : 1); };
-  const uint64_t fm = magic(FV), wm = magic((uint32_t)(p.W * (p.nd ? p.nd : 1))),
-                 em = magic(VPE - FV), vm = magic(VPE);
-  const int blocks = (p.N + 63) / 64;
-  const size_t smem = lds_bytes_overlap(p);
-#define GTE_O(VEC, NT, UU) \
-  hipLaunchKernelGGL((gte_step_overlap_kernel<VEC, NT, UU>), dim3(blocks), dim3(256), smem, stream, \
-                     p, fm, wm, em, vm)
-#define GTE_O_U(VEC, NT) GTE_O(VEC, NT, 4)  /* U = 8: 49.7 us, U = 2: 44.9 us, U = 4: 43.2 us */
-  if (vec == 4) { if (nt == 2) GTE_O_U(4, 2); else if (nt == 1) GTE_O_U(4, 1); else GTE_O_U(4, 0); }
-  else          { if (nt == 2) GTE_O_U(1, 2); else if (nt == 1) GTE_O_U(1, 1); else GTE_O_U(1, 0); }
-#undef GTE_O_U
-#undef GTE_O
-  return hipGetLastError();
-}
-
 // ---------------------------------------------------------------------------
 // L2-affinity permutation.  Workgroups are dealt round-robin over the 8 XCDs, each
 // with a private 4 MiB L2 (workgroup b and b+8 share one; observed behaviour, used

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void gte_rollout_kernel(const Params p0, const
     const Params p = step_params(p0, r, k);
     ObsJob job;
     double pv = 0.0;
-    phase_a<MODE_STEP>(p, e0, active, lane, job, nullptr, nullptr, /*compact=*/k == r.K - 1, &pv);
+    phase_a<MODE_STEP>(p, e0, active, lane, job, nullptr, /*compact=*/k == r.K - 1, &pv);
     if (owns) publish_job(R.set(k & 1), lane, job);
     if (r.valuation && active) r.valuation[(int64_t)k * p0.N + e0] = pv;
   };

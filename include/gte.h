@@ -117,9 +117,8 @@ typedef struct gte_config {
   int32_t kernel_variant;   /* 0 = auto.  Bits for A/B timing of the kernel structure:
                                1 = every wave runs phase A for its own envs (no
                                cooperative phase A), 2 = no LDS staging of the
-                               dynamic columns, 4 = overlapped step kernel (waves
-                               1-3 gather predicted windows during phase A)
-                               instead of the classic one (csrc/gte_kernels.hip),
+                               dynamic columns, 4 = retired (was the overlapped step
+                               kernel, measured slower, removed in round 2; ignored),
                                64 = launch the shared-TU instantiation of the hot
                                kernel instead of the isolated one (gte_hot.hip),
                                128 = gte_rollout runs as one launch per step even
@@ -345,7 +344,7 @@ int gte_copy_to_host(gte_env* env, const void* device_src, void* host_dst,
 
 /* kernel geometry actually used (for DESIGN.md / bench output).  *vector_bytes = bytes per
  * copy vector + 1000 * flags: bit 0 cooperative phase A, bits 1-2 staging of the dynamic
- * columns (0 none, 1 raw rings in LDS, 2 resolved in LDS), bit 3 overlapped kernel, bits 4-5
+ * columns (0 none, 1 raw rings in LDS, 2 resolved in LDS), bit 3 unused, bits 4-5
  * the observation store policy in use (0 plain, 1 nt, 2 sc1; never 3), bits 6-9 the resident
  * workgroups per CU the automatic geometry was sized for (0 = not applicable). */
 int gte_get_launch_info(gte_env* env, int32_t* envs_per_wave,

@@ -105,7 +105,9 @@ def test_return_slots_keep_older_returns_intact(oracle_mod):
     kept = []
     for k in range(25):
         a = rng.integers(-1, 3, N).astype(np.int32)
-        _, reward, term, trunc, _ = env.step(torch.from_numpy(a).cuda())
+        # the slot rotates whichever way the actions arrive: device tensor, numpy, list, CPU tensor
+        arg = (torch.from_numpy(a).cuda(), a, a.tolist(), torch.from_numpy(a))[k % 4]
+        _, reward, term, trunc, _ = env.step(arg)
         ora.step(a)
         kept.append((env.packed_returns, reward, term, trunc, ora.reward.copy(),
                      ora.terminated.astype(bool), ora.truncated.astype(bool)))

@@ -297,16 +297,74 @@ def test_hip_vs_oracle_shape_sweep(oracle_mod, shape, autoreset):
                          max_episode_duration=max_dur, autoreset=autoreset)
 
 
-@pytest.mark.parametrize("variant,store", [(4, 1), (4, 2), (4, 0), (0, 1), (0, 0), (1, 2), (2, 2),
-                                           (64, 2)])
+@pytest.mark.parametrize("variant,store", [(0, 1), (0, 2), (0, 0), (1, 2), (2, 2), (3, 1), (64, 2),
+                                           (64, 1)])
 def test_hip_vs_oracle_kernel_variants(oracle_mod, variant, store):
-    """Every selectable kernel structure (classic / overlapped / per-wave phase A / no LDS
-    staging) and store policy (plain / nt / sc1) gives the same results."""
+    """Every selectable kernel structure (isolated / shared-TU hot kernel, per-wave phase A, no
+    LDS staging) and store policy (plain / nt / sc1) gives the same results."""
     ds = [_synthetic(71, 3000, 30, sigma=1e-2)]
     _compare_with_oracle(oracle_mod, ds, n_envs=6000, steps=60, seed=41, check_every=6,
                          windows=20, positions=[-1, 0, 1], trading_fees=1e-4,
                          borrow_interest_rate=3e-6, max_episode_duration=25,
                          autoreset="next_step", kernel_variant=variant, nontemporal_obs=store)
+
+
+def test_persistent_dynamic_columns_beyond_row_32768(oracle_mod):
+    """dyn_persist keeps a T-deep dynamic column per env; the window's first ROW used to travel
+    in 15 bits of the LDS job record, so rows >= 32 768 aliased (the reference's own
+    BTC_USD-Hourly.csv has 33 259 rows).  T = 40 000, starts forced past row 32 768 + W."""
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    T, Fs, N, W = 40_000, 6, 384, 20
+    f, c = _synthetic(5, T, Fs, sigma=4e-3)
+    kw = dict(windows=W, positions=[-1, 0, 1], trading_fees=1e-4, borrow_interest_rate=3e-6,
+              max_episode_duration=12, autoreset="next_step", dyn_persist=True, seed=3)
+    env = BatchedTradingEnv((f, c), num_envs=N, output="numpy", **kw)
+    full = np.zeros((T, Fs + 2), np.float32); full[:, :Fs] = f
+    ora = oracle_mod.OracleEnv(env.cfg, [(full, c)])
+    rng = np.random.default_rng(8)
+    # a third of the envs below the old limit, the rest across and beyond it; the later
+    # auto-resets land close to the first start so that stale rows are revisited
+    start = np.where(np.arange(N) % 3 == 0, rng.integers(W - 1, 30_000, N),
+                     rng.integers(32_768 - W, 39_000, N)).astype(np.int32)
+    q = np.clip(start[:, None] + rng.integers(-6, 7, (N, 6)), W - 1, T - 40).astype(np.int32)
+    env.set_autoreset_injection(q, None, None)
+    ora.set_autoreset_injection(q, None, None)
+    env.reset(inject_idx=start)
+    ora.reset(inj_idx=start)
+    for k in range(60):
+        a = rng.integers(-1, 3, N).astype(np.int32)
+        env.step(a); ora.step(a)
+        np.testing.assert_array_equal(env.state("idx"), ora.state()["idx"])
+        np.testing.assert_array_equal(env.read_output("obs"), ora.obs, err_msg=f"step {k}")
+    assert (env.state("idx") > 32_768 + W).sum() > N // 2
+    env.close()
+
+
+def test_window_limit_and_dataset_replacement():
+    """gte_create refuses windows >= 32 768 (the job record's zero-row count has 15 bits);
+    gte_upload_dataset after a reset refuses a SHORTER table (running envs could be past its
+    end) and swaps a same-length one in without disturbing the env."""
+    from gym_trading_env_amd import _abi
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    from gym_trading_env_amd import staging
+    f, c = _synthetic(6, 70_000, 1)
+    with pytest.raises(_abi.GteError, match="32768"):
+        BatchedTradingEnv((f, c), num_envs=4, windows=32_768, dynamic_feature_functions=[],
+                          output="numpy")
+    f, c = _synthetic(7, 500, 3)
+    env = BatchedTradingEnv((f, c), num_envs=64, windows=4, output="numpy", autoreset="next_step",
+                            max_episode_duration=30)
+    env.reset()
+    for _ in range(5):
+        env.step(np.zeros(64, np.int32))
+    with pytest.raises(_abi.GteError, match="cannot replace"):
+        env.upload_dataset(0, staging.stage_arrays(f[:200], c[:200]))
+    f2 = f + 1.0
+    env.upload_dataset(0, staging.stage_arrays(f2, c))
+    obs, *_ = env.step(np.zeros(64, np.int32))
+    idx = env.state("idx")
+    np.testing.assert_array_equal(obs[:, -1, :3], f2[idx])
+    env.close()
 
 
 @pytest.mark.parametrize("windows,persist,output", [(20, False, "numpy"), (None, False, "torch"),
