@@ -15,10 +15,10 @@ __all__ = ["TradingEnv", "MultiDatasetTradingEnv", "BatchedTradingEnv", "SB3Trad
 
 _LAZY = {
     "BatchedTradingEnv": "batched", "TradingEnv": "envs",
-    "MultiDatasetTradingEnv": "envs", "basic_reward_function": "envs",
-    "dynamic_feature_last_position_taken": "envs",
-    "dynamic_feature_real_position": "envs", "History": "history",
-    "SB3TradingVecEnv": "sb3",
+    "MultiDatasetTradingEnv": "envs", "basic_reward_function": "defaults",
+    "dynamic_feature_last_position_taken": "defaults",
+    "dynamic_feature_real_position": "defaults", "History": "history",
+    "SB3TradingVecEnv": "sb3", "BatchedHistory": "batched_history", "DeviceArray": "device_array",
 }
 
 

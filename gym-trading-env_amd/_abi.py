@@ -10,7 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-GTE_ABI_VERSION = 1
+GTE_ABI_VERSION = 2
 GTE_MAX_POSITIONS = 32
 GTE_MAX_DYN = 4
 
@@ -142,6 +142,23 @@ class GteStateView(C.Structure):
     ]
 
 
+class GteLogView(C.Structure):
+    """struct gte_log_view: device pointers of the trajectory log, kept as integers."""
+
+    _fields_ = [("idx", C.c_void_p), ("step", C.c_void_p), ("position_index", C.c_void_p),
+                ("dataset_index", C.c_void_p), ("portfolio_valuation", C.c_void_p),
+                ("real_position", C.c_void_p), ("reward", C.c_void_p), ("flags", C.c_void_p),
+                ("rows", C.c_int64), ("L", C.c_int32), ("N", C.c_int32),
+                ("asset", C.c_void_p), ("fiat", C.c_void_p), ("interest_asset", C.c_void_p),
+                ("interest_fiat", C.c_void_p)]
+
+
+#: dtype of every log array
+LOG_DTYPES = {"idx": "int32", "step": "int32", "position_index": "int32", "dataset_index": "int32",
+              "portfolio_valuation": "float64", "real_position": "float64", "reward": "float64",
+              "flags": "uint8", "asset": "float64", "fiat": "float64",
+              "interest_asset": "float64", "interest_fiat": "float64"}
+
 #: dtype of every gte_state_view member, in declaration order
 STATE_DTYPES = {
     "idx": "int32", "step": "int32", "position_index": "int32",
@@ -163,7 +180,12 @@ SYMBOLS = {
                                                C.c_void_p, C.c_void_p]),
     "gte_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "gte_add_limit_orders": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "gte_get_log": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gte_get_log": (C.c_int, [C.c_void_p, _P(GteLogView)]),
+    "gte_read_log_portfolio": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 4
+                               + [_P(C.c_int32)]),
+    "gte_set_log_reward": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gte_get_final_state": (C.c_int, [C.c_void_p, _P(GteStateView)]),
+    "gte_set_dynamic_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "gte_read_log": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 8 + [_P(C.c_int32)]),
     "gte_get_outputs": (C.c_int, [C.c_void_p, _P(GteOutputs)]),
     "gte_get_state": (C.c_int, [C.c_void_p, _P(GteStateView)]),

@@ -31,61 +31,50 @@ def _as_staged(ds, n_dyn, name="Stock"):
 
 class LazyInfo(dict):
     """`info` of a batched step: struct-of-arrays view of what the reference logs in
-    `History` each step (environments.py:253-264), fetched from HBM only on access.
+    `History` each step and returns as `history[-1]` (environments.py:253-264, :272), fetched
+    from HBM only on access, one host array of length N per key.
 
-    Keys follow History's flattened column names (docs/source/history.rst:18-46):
-    idx, step, position_index, position, real_position, portfolio_valuation,
+    Keys are History's flattened column names (docs/source/history.rst:18-46,
+    docs/source/vectorize_env.rst:25-33): idx, step, date, position_index, position,
+    real_position, data_<every non-feature column of the DataFrame>, portfolio_valuation,
     portfolio_distribution_{asset,fiat,borrowed_asset,borrowed_fiat,interest_asset,
-    interest_fiat}, reward, data_close, dataset_index."""
-
-    _KEYS = ("idx", "step", "position_index", "position", "real_position",
-             "portfolio_valuation", "portfolio_distribution_asset",
-             "portfolio_distribution_fiat", "portfolio_distribution_borrowed_asset",
-             "portfolio_distribution_borrowed_fiat", "portfolio_distribution_interest_asset",
-             "portfolio_distribution_interest_fiat", "reward", "data_close", "dataset_index")
+    interest_fiat}, reward — plus dataset_index.  `_key` is Gymnasium's presence mask (all True).
+    With ``autoreset="same_step", final_obs=True`` the envs whose episode ended in this step
+    also get Gymnasium's `final_observation` / `final_info` (object arrays, `None` elsewhere)
+    with their `_final_observation` / `_final_info` masks."""
 
     def __init__(self, env):
         super().__init__()
         self._env = env
+        self._KEYS = tuple(env.info_keys)
+        self._final = bool(env.cfg.final_obs)
 
     def keys(self):
-        return list(self._KEYS)
+        return list(self._KEYS) + (["final_observation", "final_info"] if self._final else [])
 
     def __contains__(self, k):
-        return k in self._KEYS
+        return k in self._KEYS or (self._final and k in ("final_observation", "final_info",
+                                                         "_final_observation", "_final_info")) \
+            or (isinstance(k, str) and k.startswith("_") and k[1:] in self._KEYS)
 
     def __iter__(self):
-        return iter(self._KEYS)
+        return iter(self.keys())
 
     def __len__(self):
-        return len(self._KEYS)
+        return len(self.keys())
 
     def __missing__(self, key):
         e = self._env
+        if self._final and key in ("final_observation", "final_info", "_final_observation",
+                                   "_final_info"):
+            self.update(e._final_entries())
+            return dict.__getitem__(self, key)
         if key.startswith("_") and key[1:] in self._KEYS:
             # Gymnasium's vector-env convention (docs/source/vectorize_env.rst:25-33): `_key`
             # marks the envs for which `key` is present — here always all of them
             v = np.ones(e.num_envs, dtype=bool)
-            self[key] = v
-            return v
-        if key in ("idx", "step", "position_index", "real_position", "portfolio_valuation",
-                   "dataset_index"):
-            v = e.state(key)
-        elif key == "position":
-            v = np.asarray(e.positions, dtype=np.float64)[e.state("position_index")]
-        elif key == "reward":
-            v = e.read_output("reward64")
-        elif key == "data_close":
-            ds, idx = e.state("dataset_index"), e.state("idx")
-            v = np.array([e.datasets[d].close[i] for d, i in zip(ds, idx)])
-        elif key.startswith("portfolio_distribution_"):
-            # Portfolio.get_portfolio_distribution, portfolio.py:49-57
-            f = key[len("portfolio_distribution_"):]
-            if f in ("interest_asset", "interest_fiat"):
-                v = e.state(f)
-            else:
-                src = e.state("asset" if f.endswith("asset") else "fiat")
-                v = np.maximum(0.0, -src if f.startswith("borrowed") else src)
+        elif key in self._KEYS:
+            v = e._info_value(key, e.state, e.read_output("reward64") if key == "reward" else None)
         else:
             raise KeyError(key)
         self[key] = v
@@ -166,8 +155,22 @@ class BatchedTradingEnv(_VectorEnvBase):
         self._lib = _abi.load_library(library_path)  # raises if the HIP build is missing
         self._h = C.c_void_p()
 
-        from .config import resolve_dynamic_features
-        n_dyn = len(resolve_dynamic_features(dynamic_feature_functions))
+        from .config import HOST_CALLABLE, resolve_dynamic_features, resolve_reward
+        dyn_kinds = resolve_dynamic_features(dynamic_feature_functions)
+        n_dyn = len(dyn_kinds)
+        # a user's own callables (anything but this package's default objects / the string and
+        # tuple specs) are evaluated after every launch, vectorised over a BatchedHistory
+        self._dyn_callables = [(i, f) for i, (k, f) in enumerate(zip(dyn_kinds, dynamic_feature_functions))
+                               if k == HOST_CALLABLE]
+        self._reward_callable = (reward_function if resolve_reward(reward_function)[0] == HOST_CALLABLE
+                                 else None)
+        if self._dyn_callables or self._reward_callable is not None:
+            if autoreset == "same_step":
+                raise NotImplementedError(
+                    "custom reward / dynamic-feature callables need autoreset='next_step' or None: in "
+                    "same-step mode the terminal History row an env's callable would see is replaced "
+                    "by the reset row inside the launch")
+            log_steps = max(int(log_steps), 2)  # the callables read h[..., -1] and h[..., -2]
         raw = list(df) if isinstance(df, (list, tuple)) and not (
             isinstance(df, tuple) and len(df) in (2, 4) and hasattr(df[0], "shape")) else [df]
         self.datasets = [_as_staged(d, n_dyn, name) for d in raw]
@@ -190,6 +193,10 @@ class BatchedTradingEnv(_VectorEnvBase):
             kernel_variant=kernel_variant, debug_flags=debug_flags,
             affinity_period=affinity_period, final_obs=final_obs, log_steps=log_steps)
         self.log_metrics = []
+        from .batched_history import history_columns
+        self.info_keys = history_columns(self) + ["dataset_index"]
+        self._ds_offsets = np.concatenate([[0], np.cumsum([d.T for d in self.datasets])]).astype(np.int64)
+        self._host_columns, self._dev_columns = {}, {}
         _abi.check(self._lib, self._lib.gte_create(C.byref(self.cfg), C.byref(self._h)))
 
         self.n_obs = first.n_static + n_dyn
@@ -203,6 +210,8 @@ class BatchedTradingEnv(_VectorEnvBase):
         for d, s in enumerate(self.datasets):
             self.upload_dataset(d, s)
 
+        self._final_view, self._final_epoch = _abi.GteStateView(), -1
+        self._logv, self._log_tensors, self._pos_table = _abi.GteLogView(), {}, None
         self._state = _abi.GteStateView()
         self._epoch, self._state_epoch = 0, -1  # state snapshots are taken lazily
         self._snap_epoch, self._snap, self._snap_obs = -1, None, None  # numpy mode, per step
@@ -364,6 +373,222 @@ class BatchedTradingEnv(_VectorEnvBase):
             return ids, self._t["final_obs"][idx]
         return ids, self.read_output("final_obs")[ids]
 
+
+    # -- vectorised access to what History logs (LazyInfo, BatchedHistory, metrics) ------------
+    def _dataset_host_column(self, name):
+        """One column of every dataset's info table (`data_<col>`, environments.py:142,260) or
+        the index (`date`, :256), concatenated over the datasets: a (dataset, row) pair is ONE
+        fancy index away, whatever N."""
+        col = self._host_columns.get(name)
+        if col is None:
+            parts = []
+            for ds in self.datasets:
+                if name == "date":
+                    parts.append(np.asarray(ds.index) if ds.index is not None else np.arange(ds.T))
+                    continue
+                c = name[len("data_"):]
+                if ds.info_array is not None and c in ds.info_columns:
+                    parts.append(ds.info_array[:, ds.info_columns.index(c)])
+                elif c == "close":
+                    parts.append(ds.close)
+                else:
+                    raise ValueError(f"Feature {name} does not exist ... Check the available "
+                                     f"features : {self.info_keys}")
+            col = np.concatenate(parts) if len(parts) > 1 else np.asarray(parts[0])
+            if col.dtype == object:  # a numeric column staged through an object matrix
+                try:
+                    col = col.astype(np.float64)
+                except (TypeError, ValueError):
+                    pass
+            self._host_columns[name] = col
+        return col
+
+    def _dataset_column(self, name, ds, idx):
+        """Values of info column `name` at (dataset, row) pairs; on the device for numeric
+        columns in torch mode, else host arrays."""
+        col = self._dataset_host_column(name)
+        torch = self._torch
+        if torch is not None and isinstance(ds, torch.Tensor):
+            if col.dtype.kind in "fiub":
+                dev = self._dev_columns.get(name)
+                if dev is None:
+                    dev = torch.as_tensor(col, device=ds.device)
+                    self._dev_columns[name] = dev
+                    self._dev_offsets = torch.as_tensor(self._ds_offsets, device=ds.device)
+                return dev[self._dev_offsets[ds.long()] + idx.long()]
+            ds, idx = ds.cpu().numpy(), idx.cpu().numpy()
+        return col[self._ds_offsets[np.asarray(ds)] + np.asarray(idx)]
+
+    def _info_value(self, key, state, reward=None):
+        """One `info` / History column for every env from a struct-of-arrays state reader
+        (`state(name) -> host array`): the current state, or the terminal one."""
+        if key in ("idx", "step", "position_index", "real_position", "portfolio_valuation",
+                   "dataset_index"):
+            return state(key)
+        if key == "position":
+            return np.asarray(self.positions, dtype=np.float64)[state("position_index")]
+        if key == "reward":
+            return reward
+        if key == "date" or key.startswith("data_"):
+            return self._dataset_column(key, state("dataset_index"), state("idx"))
+        if key.startswith("portfolio_distribution_"):
+            # Portfolio.get_portfolio_distribution, portfolio.py:49-57
+            f = key[len("portfolio_distribution_"):]
+            if f in ("interest_asset", "interest_fiat"):
+                return state(f)
+            src = state("asset" if f.endswith("asset") else "fiat")
+            return np.maximum(0.0, -src if f.startswith("borrowed") else src)
+        raise KeyError(key)
+
+    def final_state(self, name: str) -> np.ndarray:
+        """Host copy of one per-env array of the TERMINAL states (`gte_get_final_state`): row e
+        is env e as it was when its last episode ended (same-step mode with final_obs)."""
+        if self._final_epoch != self._epoch:
+            _abi.check(self._lib, self._lib.gte_get_final_state(self._h, C.byref(self._final_view)))
+            self._final_epoch = self._epoch
+        return self._to_host(getattr(self._final_view, name), _NP[_abi.STATE_DTYPES[name]],
+                             self.num_envs)
+
+    def _final_entries(self) -> dict:
+        """Gymnasium's `final_observation` / `final_info` (+ masks) for the envs that ended in
+        the last step: the observation and the History row `TradingEnv.step` returned for them
+        (environments.py:272) before the same-step reset."""
+        N = self.num_envs
+        ids, last = self.final_observations()
+        mask = np.zeros(N, dtype=bool)
+        mask[ids] = True
+        f_obs = np.full(N, None, dtype=object)
+        f_info = np.full(N, None, dtype=object)
+        if len(ids):
+            reward = self.read_output("reward64")  # the terminal step's reward (same-step mode)
+            cols = {k: np.asarray(self._info_value(k, self.final_state, reward))[ids]
+                    for k in self.info_keys}
+            for j, e in enumerate(ids):
+                f_obs[e] = last[j]
+                f_info[e] = {k: v[j] for k, v in cols.items()}
+        return {"final_observation": f_obs, "_final_observation": mask,
+                "final_info": f_info, "_final_info": mask.copy()}
+
+    # -- the device trajectory log ---------------------------------------------------------------
+    def _log_view(self):
+        _abi.check(self._lib, self._lib.gte_get_log(self._h, C.byref(self._logv)))
+        return self._logv
+
+    def _log_tensor(self, name):
+        """torch view [L, N] of one log array (no copy)."""
+        t = self._log_tensors.get(name)
+        if t is None:
+            v, dt = self._log_view(), np.dtype(_abi.LOG_DTYPES[name])
+
+            class _Raw:
+                __cuda_array_interface__ = {
+                    "shape": (int(v.L), int(v.N)), "typestr": dt.str, "version": 2, "strides": None,
+                    "data": (int(getattr(v, name)), False)}
+            t = self._torch.as_tensor(_Raw(), device=self._t["obs"].device)
+            self._log_tensors[name] = t
+        return t
+
+    def _log_rows(self, name, phys, order):
+        """Log column `name`: physical row `phys` ([N]), per-env rows `phys[N]` ([N]), or — phys
+        None — the rows `order`, oldest first ([R, N])."""
+        N = self.num_envs
+        if self._torch is not None:
+            t = self._log_tensor(name)
+            if phys is None:
+                return t[self._torch.as_tensor(order, device=t.device)]
+            if np.ndim(phys) == 0:
+                return t[int(phys)]
+            return t[phys.long(), self._torch.arange(N, device=t.device)]
+        v, dt = self._log_view(), np.dtype(_abi.LOG_DTYPES[name])
+        base = int(getattr(v, name))
+        if phys is not None and np.ndim(phys) == 0:
+            return self._to_host(base + int(phys) * N * dt.itemsize, dt, N)
+        whole = self._to_host(base, dt, int(v.L) * N).reshape(int(v.L), N)
+        return whole[order] if phys is None else whole[np.asarray(phys), np.arange(N)]
+
+    def _log_row(self, name, phys, raw=False):
+        return self._log_rows(name, phys, None)
+
+    def _wrap(self, x):
+        """What user callables receive: DeviceArray around device tensors, host arrays as is."""
+        if self._torch is not None and isinstance(x, self._torch.Tensor):
+            from .device_array import DeviceArray
+            return DeviceArray(x)
+        return x
+
+    def _positions_table(self):
+        if self._torch is None:
+            return np.asarray(self.positions, dtype=np.float64)
+        if self._pos_table is None:
+            self._pos_table = self._torch.tensor(self.positions, dtype=self._torch.float64,
+                                                 device=self._t["obs"].device)
+        return self._pos_table
+
+    def _take(self, table, index):
+        return table[index.long()] if self._torch is not None else table[index]
+
+    def _relu(self, x):
+        return x.clamp_min(0.0) if self._torch is not None else np.maximum(0.0, x)
+
+    def _stack(self, cols):
+        return self._torch.stack(cols, dim=-1) if self._torch is not None else np.stack(cols, axis=-1)
+
+    def _arange_rows(self, n):
+        if self._torch is not None:
+            return self._torch.arange(n, device=self._t["obs"].device)
+        return np.arange(n)
+
+    def _set_log_reward(self, value):
+        """`historical_info["reward", -1] = reward` (environments.py:267) for the batch."""
+        if self._torch is not None:
+            from .device_array import to_tensor
+            r = to_tensor(value, self._t["obs"].device, self._torch.float64).contiguous()
+            self._keep_reward = r
+            _abi.check(self._lib, self._lib.gte_set_log_reward(self._h, C.c_void_p(r.data_ptr())))
+        else:
+            raise NotImplementedError("assigning log rewards needs output='torch'")
+
+    def batched_history(self):
+        """The `BatchedHistory` of the batch right now (needs ``log_steps``): what custom reward /
+        dynamic-feature / metric callables receive."""
+        from .batched_history import BatchedHistory
+        return BatchedHistory(self)
+
+    def _apply_callables(self, after_reset: bool):
+        """The user's own `reward_function` / `dynamic_feature_functions` (any callable that is
+        not this package's default object), evaluated ONCE for the whole batch over a
+        BatchedHistory, where the reference calls them per env: reward after `History.add`
+        (environments.py:265-267: skipped — reward 0 — when done; rows a reset wrote have reward
+        0, :196), then the dynamic features inside `_get_obs` (:153-154), which therefore see the
+        reward."""
+        if self._reward_callable is None and not self._dyn_callables:
+            return
+        torch = self._torch
+        if torch is None:
+            raise NotImplementedError("custom callables in the batch need output='torch'")
+        from .device_array import to_tensor
+        dev = self._t["obs"].device
+        h = self.batched_history()
+        if self._reward_callable is not None and not after_reset:
+            r = to_tensor(self._reward_callable(h), dev, torch.float64)
+            if r.shape != (self.num_envs,):
+                raise ValueError(f"reward_function must return one value per env, got shape {tuple(r.shape)}")
+            newest = (h._rows - 1) % h._L
+            skip = self._t["terminated"] | (self._log_tensor("step")[newest] == 0)
+            r = torch.where(skip, torch.zeros_like(r), r)
+            self._t["reward64"].copy_(r)
+            self._t["reward"].copy_(r.to(torch.float32))
+            h["reward", -1] = r
+        if self._dyn_callables:
+            vals = torch.zeros((self.num_envs, self.cfg.n_dyn), dtype=torch.float32, device=dev)
+            mask = 0
+            for i, fn in self._dyn_callables:
+                vals[:, i] = to_tensor(fn(h), dev, torch.float32)
+                mask |= 1 << i
+            self._keep_dyn = vals
+            _abi.check(self._lib, self._lib.gte_set_dynamic_features(
+                self._h, C.c_void_p(vals.data_ptr()), mask))
+
     # -- trajectory log ------------------------------------------------------------------
     def add_metric(self, name, function):
         """`TradingEnv.add_metric` (environments.py:274-278): `function(history)` is evaluated
@@ -374,8 +599,10 @@ class BatchedTradingEnv(_VectorEnvBase):
 
     def history(self, env_id: int):
         """The current (or just finished) episode of one env as a `History` with the
-        reference's columns (environments.py:186-197, 253-264), rebuilt from the device
-        trajectory log.  Episodes longer than ``log_steps`` are truncated at the front."""
+        reference's columns (environments.py:186-197, 253-264: idx, step, date, position_index,
+        position, real_position, data_*, portfolio_valuation, portfolio_distribution_*, reward),
+        rebuilt from the device trajectory log.  Episodes longer than ``log_steps`` are
+        truncated at the front."""
         from .history import History
         L = int(self.cfg.log_steps)
         if not L:
@@ -384,29 +611,38 @@ class BatchedTradingEnv(_VectorEnvBase):
                 "pos": np.empty(L, np.int32), "ds": np.empty(L, np.int32),
                 "pv": np.empty(L, np.float64), "rp": np.empty(L, np.float64),
                 "rew": np.empty(L, np.float64), "flags": np.empty(L, np.uint8)}
+        port = {k: np.empty(L, np.float64) for k in ("asset", "fiat", "ia", "ifi")}
         n = C.c_int32()
         _abi.check(self._lib, self._lib.gte_read_log(
             self._h, int(env_id), L, *(b.ctypes.data for b in bufs.values()), C.byref(n)))
+        _abi.check(self._lib, self._lib.gte_read_log_portfolio(
+            self._h, int(env_id), L, *(b.ctypes.data for b in port.values()), C.byref(n)))
         n = n.value
         step = bufs["step"][:n]
         # the episode = the last run of rows whose step counts 0, 1, 2, ...
         start = n - 1
         while start > 0 and step[start - 1] == step[start] - 1:
             start -= 1
-        h = History(max_size=max(n - start, 1))
-        positions = self.positions
-        for k in range(start, n):
-            d, t, pi = int(bufs["ds"][k]), int(bufs["idx"][k]), int(bufs["pos"][k])
-            ds = self.datasets[d]
-            data = ({c: ds.info_array[t, j] for j, c in enumerate(ds.info_columns)}
-                    if ds.info_array is not None else {"close": ds.close[t]})
-            row = dict(idx=t, step=int(step[k]),
-                       date=ds.index[t] if ds.index is not None else t,
-                       position_index=pi, position=positions[pi],
-                       real_position=float(bufs["rp"][k]), data=data,
-                       portfolio_valuation=float(bufs["pv"][k]), reward=float(bufs["rew"][k]))
-            (h.set if k == start else h.add)(**row)
-        return h
+        sl = slice(start, n)
+        ds, idx, pos = bufs["ds"][sl], bufs["idx"][sl], bufs["pos"][sl]
+        asset, fiat = port["asset"][sl], port["fiat"][sl]
+        cols = {"idx": idx.tolist(), "step": step[sl].tolist(),
+                "date": list(self._dataset_column("date", ds, idx)),
+                "position_index": pos.tolist(),
+                "position": [self.positions[i] for i in pos],
+                "real_position": bufs["rp"][sl].tolist()}
+        for c in self.datasets[0].info_columns or ["close"]:
+            cols[f"data_{c}"] = list(self._dataset_column(f"data_{c}", ds, idx))
+        cols["portfolio_valuation"] = bufs["pv"][sl].tolist()
+        # Portfolio.get_portfolio_distribution, portfolio.py:49-57
+        cols["portfolio_distribution_asset"] = np.maximum(0, asset).tolist()
+        cols["portfolio_distribution_fiat"] = np.maximum(0, fiat).tolist()
+        cols["portfolio_distribution_borrowed_asset"] = np.maximum(0, -asset).tolist()
+        cols["portfolio_distribution_borrowed_fiat"] = np.maximum(0, -fiat).tolist()
+        cols["portfolio_distribution_interest_asset"] = port["ia"][sl].tolist()
+        cols["portfolio_distribution_interest_fiat"] = port["ifi"][sl].tolist()
+        cols["reward"] = bufs["rew"][sl].tolist()
+        return History.from_columns(cols)
 
     def save_for_render(self, env_id: int, dir="render_logs"):
         """`TradingEnv.save_for_render` (environments.py:296-307) for one env of the batch: the
@@ -435,18 +671,20 @@ class BatchedTradingEnv(_VectorEnvBase):
         "Market Return" = close[idx] / close[start_idx] - 1 and "Portfolio Return" =
         portfolio_valuation / initial value - 1, as float arrays plus the reference's
         formatted strings.  Call it right after the terminal step (with next-step auto-reset
-        the state still belongs to the finished episode until the following step)."""
+        the state still belongs to the finished episode until the following step; with
+        same-step auto-reset and ``final_obs`` the terminal records are used)."""
         ids = self.terminal_ids() if env_ids is None else np.asarray(env_ids, dtype=np.int64)
-        ds, idx, start = (self.state(k)[ids] for k in ("dataset_index", "idx", "start_idx"))
-        pv = self.state("portfolio_valuation")[ids]
-        close_now = np.array([self.datasets[d].close[i] for d, i in zip(ds, idx)], dtype=np.float64)
-        close_0 = np.array([self.datasets[d].close[i] for d, i in zip(ds, start)], dtype=np.float64)
+        state = self.final_state if (self.cfg.final_obs and env_ids is None) else self.state
+        ds, idx, start = (state(k)[ids] for k in ("dataset_index", "idx", "start_idx"))
+        pv = state("portfolio_valuation")[ids]
+        close_now = np.asarray(self._dataset_column("data_close", ds, idx), dtype=np.float64)
+        close_0 = np.asarray(self._dataset_column("data_close", ds, start), dtype=np.float64)
         market = close_now / close_0 - 1 if len(ids) else np.zeros(0)
         portfolio = pv / self.cfg.portfolio_initial_value - 1
         out = {"env_ids": ids, "market_return": market, "portfolio_return": portfolio,
-               "episode_length": self.state("step")[ids] + 1,
-               "Market Return": [f"{100 * m:5.2f}%" for m in market],
-               "Portfolio Return": [f"{100 * r:5.2f}%" for r in portfolio]}
+               "episode_length": state("step")[ids] + 1,
+               "Market Return": [f"{100 * m:5.2f}%" for m in market.tolist()],
+               "Portfolio Return": [f"{100 * r:5.2f}%" for r in portfolio.tolist()]}
         if self.log_metrics:  # custom metrics over each finished env's History (:285-286)
             hists = [self.history(int(e)) for e in ids]
             for metric in self.log_metrics:
@@ -507,6 +745,7 @@ class BatchedTradingEnv(_VectorEnvBase):
         _abi.check(self._lib, self._lib.gte_reset(self._h, mp, ap, bp, cp))
         self._was_reset = True
         self._epoch += 1
+        self._apply_callables(after_reset=True)
         return self._results()[0], LazyInfo(self)
 
     def set_autoreset_injection(self, idx=None, position_index=None, dataset=None):
@@ -542,6 +781,7 @@ class BatchedTradingEnv(_VectorEnvBase):
         A torch int32 CUDA tensor is used in place; anything else goes through a
         host->device copy."""
         self._launch_step(actions)
+        self._apply_callables(after_reset=False)
         obs, reward, term, trunc = self._results()
         return obs, reward, term, trunc, LazyInfo(self)
 
@@ -620,6 +860,9 @@ class BatchedTradingEnv(_VectorEnvBase):
         torch = self._torch
         if torch is None:
             raise ValueError("rollout needs output='torch'")
+        if self._reward_callable is not None or self._dyn_callables:
+            raise NotImplementedError("a fused rollout runs all steps on the device: custom Python "
+                                      "reward / dynamic-feature callables need step()")
         dev = self._t["obs"].device
         if not (isinstance(actions, torch.Tensor) and actions.is_cuda):
             a = np.asarray([[-1 if x is None else x for x in row] for row in actions]

@@ -10,8 +10,12 @@ import ctypes as C
 
 from . import _abi
 
-#: reward functions that run on device, by the name of the Python callable the
-#: reference / its fork uses (environments.py:17, luckymodel/envs/env.py:16)
+from . import defaults
+
+#: rewards the device computes, by EXPLICIT spec: a string, or a tuple carrying parameters
+#: ("scaled_log_return", k) / ("clipped_log_return", k, lo, hi) — the fork's forms
+#: (luckymodel/envs/env.py:16-18).  Callables are never matched by name: only this package's
+#: own default object (identity) maps to the device; see resolve_reward.
 _REWARD_BY_NAME = {
     "basic_reward_function": _abi.REWARD_LOG_RETURN,
     "log_return": _abi.REWARD_LOG_RETURN,
@@ -24,53 +28,76 @@ _DYN_BY_NAME = {
     "dynamic_feature_real_position": _abi.DYN_REAL_POSITION,
     "real_position": _abi.DYN_REAL_POSITION,
 }
+_DYN_BY_OBJECT = {
+    defaults.dynamic_feature_last_position_taken: _abi.DYN_LAST_POSITION,
+    defaults.dynamic_feature_real_position: _abi.DYN_REAL_POSITION,
+}
 _AUTORESET_BY_NAME = {
     None: _abi.AUTORESET_DISABLED, "disabled": _abi.AUTORESET_DISABLED,
     "next_step": _abi.AUTORESET_NEXT_STEP, "same_step": _abi.AUTORESET_SAME_STEP,
 }
 
+#: what resolve_* answer for a user's own Python callable (evaluated outside the kernel)
+HOST_CALLABLE = -1
+
+
+def device_dynamic_kind(f):
+    """Device enum of one `dynamic_feature_functions` entry, or HOST_CALLABLE.
+
+    On device: this package's two default objects (by identity), the enum ints, and the
+    string specs.  ANY other callable is the user's code and is evaluated as such."""
+    if isinstance(f, bool):
+        raise TypeError(f"dynamic feature {f!r} is neither a callable nor a spec")
+    if isinstance(f, int):
+        if f not in (_abi.DYN_LAST_POSITION, _abi.DYN_REAL_POSITION):
+            raise ValueError(f"unknown dynamic feature enum {f}")
+        return int(f)
+    if isinstance(f, str):
+        if f not in _DYN_BY_NAME:
+            raise ValueError(f"unknown dynamic feature {f!r}; known: {sorted(_DYN_BY_NAME)}")
+        return _DYN_BY_NAME[f]
+    if callable(f):
+        try:
+            return _DYN_BY_OBJECT.get(f, HOST_CALLABLE)
+        except TypeError:  # unhashable callable object
+            return HOST_CALLABLE
+    raise TypeError(f"dynamic feature {f!r} is neither a callable nor a spec")
+
 
 def resolve_dynamic_features(dynamic_feature_functions) -> list[int]:
-    """Map the reference's `dynamic_feature_functions` list onto device enums.
-
-    Arbitrary Python callables over a `History` cannot run inside a HIP kernel;
-    they are refused with a clear error."""
-    kinds = []
-    for f in dynamic_feature_functions:
-        if isinstance(f, int) and f in (_abi.DYN_LAST_POSITION, _abi.DYN_REAL_POSITION):
-            kinds.append(int(f))
-            continue
-        name = f if isinstance(f, str) else getattr(f, "__name__", None)
-        if name not in _DYN_BY_NAME:
-            raise NotImplementedError(
-                f"dynamic feature {f!r} cannot run on device; supported: "
-                f"{sorted(set(_DYN_BY_NAME))}")
-        kinds.append(_DYN_BY_NAME[name])
+    """Map the reference's `dynamic_feature_functions` list onto device enums; HOST_CALLABLE
+    marks the entries that are the user's own callables."""
+    kinds = [device_dynamic_kind(f) for f in dynamic_feature_functions]
     if len(kinds) > _abi.GTE_MAX_DYN:
         raise ValueError(f"at most {_abi.GTE_MAX_DYN} dynamic features")
     return kinds
 
 
 def resolve_reward(reward_function) -> tuple[int, float, float, float]:
-    """Map `reward_function` onto (kind, param0, param1, param2).
+    """Map `reward_function` onto (kind, param0, param1, param2); kind == HOST_CALLABLE for a
+    user's own callable.
 
-    Accepts the reference's default callable, a name, or a tuple
-    ("scaled_log_return", k) / ("clipped_log_return", k, lo, hi), i.e.
+    On device: this package's `basic_reward_function` object (identity), a string spec, or a
+    tuple ("scaled_log_return", k) / ("clipped_log_return", k, lo, hi), i.e.
     np.clip(k * log_return, lo, hi) (luckymodel/envs/env.py:16-18)."""
     if isinstance(reward_function, tuple):
         name, *params = reward_function
+        if name not in _REWARD_BY_NAME:
+            raise ValueError(f"unknown reward spec {name!r}; known: {sorted(_REWARD_BY_NAME)}")
         kind = _REWARD_BY_NAME[name]
         p = [float(x) for x in params] + [1.0, 0.0, 0.0][len(params):]
         if kind == _abi.REWARD_CLIPPED_LOG_RETURN and not p[1] <= p[2]:
             raise ValueError("clipped_log_return needs lo <= hi")
         return kind, p[0], p[1], p[2]
-    name = reward_function if isinstance(reward_function, str) else getattr(
-        reward_function, "__name__", None)
-    if name not in _REWARD_BY_NAME:
-        raise NotImplementedError(
-            f"reward function {reward_function!r} cannot run on device; supported: "
-            f"{sorted(_REWARD_BY_NAME)} (tuples carry parameters)")
-    return _REWARD_BY_NAME[name], 1.0, 0.0, 0.0
+    if isinstance(reward_function, str):
+        if reward_function not in _REWARD_BY_NAME:
+            raise ValueError(f"unknown reward spec {reward_function!r}; known: {sorted(_REWARD_BY_NAME)}")
+        return _REWARD_BY_NAME[reward_function], 1.0, 0.0, 0.0
+    if reward_function is defaults.basic_reward_function:
+        return _abi.REWARD_LOG_RETURN, 1.0, 0.0, 0.0
+    if callable(reward_function):
+        return HOST_CALLABLE, 1.0, 0.0, 0.0
+    raise TypeError(f"reward_function {reward_function!r} is neither a callable nor a spec")
 
 
 def make_config(*, n_envs: int, n_static: int, n_datasets: int = 1,
@@ -103,7 +130,13 @@ def make_config(*, n_envs: int, n_static: int, n_datasets: int = 1,
     if episodes_between_dataset_switch < 1:
         raise ValueError("episodes_between_dataset_switch must be >= 1")
     kinds = resolve_dynamic_features(dynamic_feature_functions)
+    # a user's callable keeps a device placeholder: the kernel's value for that column is
+    # overwritten after every launch (gte_set_dynamic_features) / the kernel's log-return is
+    # replaced by the callable's value
+    kinds = [_abi.DYN_LAST_POSITION if k == HOST_CALLABLE else k for k in kinds]
     rk, rp0, rp1, rp2 = resolve_reward(reward_function)
+    if rk == HOST_CALLABLE:
+        rk = _abi.REWARD_LOG_RETURN
     if autoreset not in _AUTORESET_BY_NAME:
         raise ValueError(f"autoreset must be one of {list(_AUTORESET_BY_NAME)}")
 

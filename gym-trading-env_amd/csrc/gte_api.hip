@@ -30,8 +30,13 @@ int hot_blocks_per_cu(size_t smem);
 int hot_blocks_per_cu_nt(size_t smem);
 struct RolloutArgs {  // mirrors gte_rollout.hip
   const int32_t* actions; int32_t K; float* obs; float* reward; double* reward64;
-  uint8_t* terminated; uint8_t* truncated; double* valuation;
+  uint8_t* terminated; uint8_t* truncated; double* valuation; int32_t epb;
 };
+size_t resident_lds_bytes(const Params& p, int epb);
+int resident_blocks_per_cu(const Params& p, int epb, int nt);
+hipError_t launch_rollout_resident(const Params& p, const RolloutArgs& r, int nt, hipStream_t stream);
+hipError_t launch_rollout_state(const Params& p, const RolloutArgs& r, int n_steps, int epw,
+                                hipStream_t stream);
 hipError_t launch_rollout(const Params& p, const RolloutArgs& r, int nt, int blocks, int threads,
                           hipStream_t stream);
 int rollout_blocks_per_cu(const Params& p, int nt);
@@ -45,6 +50,7 @@ struct LogArrays {
   int32_t *idx, *step, *pos, *dsi;
   double *pv, *realpos, *reward;
   uint8_t* flags;
+  double *asset, *fiat, *ia, *ifi;
 };
 hipError_t launch_log(const EnvRec* rec, const double* reward64, const uint8_t* term,
                       const uint8_t* trunc, int n, int64_t row_base, const LogArrays& o,
@@ -52,6 +58,7 @@ hipError_t launch_log(const EnvRec* rec, const double* reward64, const uint8_t* 
 hipError_t launch_snapshot(const EnvRec* rec, const double* reward64, const uint8_t* term,
                            const uint8_t* trunc, const float* obs, int64_t obs_elems, int first,
                            int count, void* dst, float* dst_obs, hipStream_t stream);
+hipError_t launch_set_dynamic(const Params& p, const float* values, uint32_t mask, hipStream_t stream);
 hipError_t launch_affinity_rebuild(const Params& p, int32_t* bins, int n_bins_per_ds,
                                    const int32_t* slot_of_rank, int32_t* perm_out,
                                    hipStream_t stream);
@@ -116,9 +123,12 @@ struct gte_env {
   int32_t* d_slot_of_rank = nullptr;
   int32_t* d_bins = nullptr;
   gte::StateSoA soa = {};  // host-facing struct-of-arrays mirrors (gte_get_state)
+  gte::StateSoA fsoa = {}; // the same for the terminal records (gte_get_final_state)
   gte::LogArrays log = {}; // device trajectory log (cfg.log_steps rows per env)
   int64_t log_rows = 0;
   int rollout_epw = 0;     // envs per wavefront of the fused rollout kernel (0 = not chosen yet)
+  int resident_epb[3] = {0, 0, 0};  // envs per workgroup of the window-resident rollout kernel per
+                                    // store policy (0 = not chosen yet, -1 = shape not covered)
   int hot_per_cu = 0;      // resident workgroups per CU the geometry was sized for (0 = n/a)
   bool store_auto = false; // the observation store policy was chosen here (cfg said 3)
   void* h_snap = nullptr;  // pinned host memory for gte_read_envs: snapshots, then observations
@@ -271,7 +281,17 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   chk(dev_alloc(E, &E->soa.ia, N)); chk(dev_alloc(E, &E->soa.ifi, N));
   chk(dev_alloc(E, &E->soa.pv, N)); chk(dev_alloc(E, &E->soa.realpos, N));
   chk(dev_alloc(E, &E->owned.obs, N * p.W * p.Fobs));
-  if (cfg->final_obs) chk(dev_alloc(E, &E->owned.final_obs, N * p.W * p.Fobs));
+  if (cfg->final_obs) {
+    chk(dev_alloc(E, &E->owned.final_obs, N * p.W * p.Fobs));
+    chk(dev_alloc(E, &p.final_rec, N));
+    chk(dev_alloc(E, &E->fsoa.idx, N)); chk(dev_alloc(E, &E->fsoa.step, N));
+    chk(dev_alloc(E, &E->fsoa.pos, N)); chk(dev_alloc(E, &E->fsoa.dsi, N));
+    chk(dev_alloc(E, &E->fsoa.start, N)); chk(dev_alloc(E, &E->fsoa.episode, N));
+    chk(dev_alloc(E, &E->fsoa.needs_reset, N));
+    chk(dev_alloc(E, &E->fsoa.asset, N)); chk(dev_alloc(E, &E->fsoa.fiat, N));
+    chk(dev_alloc(E, &E->fsoa.ia, N)); chk(dev_alloc(E, &E->fsoa.ifi, N));
+    chk(dev_alloc(E, &E->fsoa.pv, N)); chk(dev_alloc(E, &E->fsoa.realpos, N));
+  }
   chk(dev_alloc(E, &E->owned.reward, N)); chk(dev_alloc(E, &E->owned.reward64, N));
   chk(dev_alloc(E, &E->owned.terminated, N)); chk(dev_alloc(E, &E->owned.truncated, N));
   chk(dev_alloc(E, &E->owned.term_count, 2)); chk(dev_alloc(E, &E->owned.term_ids, N));
@@ -284,6 +304,8 @@ int gte_create(const gte_config* cfg, gte_env** out) {
     chk(dev_alloc(E, &E->log.pos, LN)); chk(dev_alloc(E, &E->log.dsi, LN));
     chk(dev_alloc(E, &E->log.pv, LN)); chk(dev_alloc(E, &E->log.realpos, LN));
     chk(dev_alloc(E, &E->log.reward, LN)); chk(dev_alloc(E, &E->log.flags, LN));
+    chk(dev_alloc(E, &E->log.asset, LN)); chk(dev_alloc(E, &E->log.fiat, LN));
+    chk(dev_alloc(E, &E->log.ia, LN)); chk(dev_alloc(E, &E->log.ifi, LN));
   }
   double* d_pos = nullptr;
   chk(dev_alloc(E, &d_pos, GTE_MAX_POSITIONS));
@@ -640,7 +662,7 @@ int gte_rollout(gte_env* E, const int32_t* actions, int32_t n_steps, const gte_r
   if (b->obs && ((uintptr_t)b->obs & 15)) return fail(GTE_ERR_INVALID, "obs must be 16-byte aligned");
   HIPCHK(hipSetDevice(E->cfg.device));
   // kernel_variant 128 = never fused (A/B and tests of the per-launch path)
-  const bool fused = E->vec == 4 && E->coop && E->stage == 1 && !E->cfg.final_obs &&
+  const bool fused = E->vec == 4 && E->coop && E->stage == 1 && !E->cfg.final_obs && !E->p.persist &&
                      E->cfg.log_steps == 0 && !(E->cfg.kernel_variant & 128);
   // per-step observation rows are written once and not read back by the kernels: a stream
   struct RestoreStorePolicy {  // whatever path leaves this function, the env's policy returns
@@ -649,68 +671,138 @@ int gte_rollout(gte_env* E, const int32_t* actions, int32_t n_steps, const gte_r
     ~RestoreStorePolicy() { slot = value; }
   } restore_store_policy{E->cfg.nontemporal_obs, E->cfg.nontemporal_obs};
   if (b->obs && E->store_auto) E->cfg.nontemporal_obs = 1;
-  if (!fused) {
-    // same results, one launch per step: point the step kernel at row k of every buffer
-    const Params keep = E->p;
-    int rc = GTE_OK;
-    for (int32_t k = 0; k < n_steps && rc == GTE_OK; ++k) {
-      if (b->obs) E->p.obs = b->obs + (size_t)k * N * V;
-      if (b->reward) E->p.reward = b->reward + (size_t)k * N;
-      if (b->reward64) E->p.reward64 = b->reward64 + (size_t)k * N;
-      if (b->terminated) E->p.terminated = b->terminated + (size_t)k * N;
-      if (b->truncated) E->p.truncated = b->truncated + (size_t)k * N;
-      rc = gte_step(E, actions + (size_t)k * N, 1);
-      if (rc == GTE_OK && b->valuation) {
-        hipError_t e = gte::launch_extract_state(E->p.rec, E->p.N, E->soa, E->stream);
-        if (e == hipSuccess)
-          e = hipMemcpyAsync(b->valuation + (size_t)k * N, E->soa.pv, 8 * N, hipMemcpyDeviceToDevice,
-                             E->stream);
-        if (e != hipSuccess) rc = fail(GTE_ERR_HIP, "rollout: %s", hipGetErrorString(e));
-      }
+  // one step as its own launch, writing row k of every per-step buffer (what the unfused path
+  // does for every step, and the backtest path for its last one)
+  const Params keep = E->p;
+  auto step_row = [&](int32_t k) -> int {
+    if (b->obs) E->p.obs = b->obs + (size_t)k * N * V;
+    if (b->reward) E->p.reward = b->reward + (size_t)k * N;
+    if (b->reward64) E->p.reward64 = b->reward64 + (size_t)k * N;
+    if (b->terminated) E->p.terminated = b->terminated + (size_t)k * N;
+    if (b->truncated) E->p.truncated = b->truncated + (size_t)k * N;
+    int rc = gte_step(E, actions + (size_t)k * N, 1);
+    if (rc == GTE_OK && b->valuation) {
+      hipError_t e = gte::launch_extract_state(E->p.rec, E->p.N, E->soa, E->stream);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(b->valuation + (size_t)k * N, E->soa.pv, 8 * N, hipMemcpyDeviceToDevice,
+                           E->stream);
+      if (e != hipSuccess) rc = fail(GTE_ERR_HIP, "rollout: %s", hipGetErrorString(e));
     }
     E->p.obs = keep.obs; E->p.reward = keep.reward; E->p.reward64 = keep.reward64;
     E->p.terminated = keep.terminated; E->p.truncated = keep.truncated;
-    if (rc != GTE_OK) return rc;
-  } else {
+    return rc;
+  };
+  auto count_steps = [&](int32_t n) -> int {  // the processing order ages with every fused step too
     if (E->affinity_period > 0) {
-      E->steps_since_rebuild += n_steps;
+      E->steps_since_rebuild += n;
       if (E->steps_since_rebuild >= E->affinity_period) {
         HIPCHK(gte::launch_affinity_rebuild(E->p, E->d_bins, E->n_bins_per_ds, E->d_slot_of_rank,
                                             E->d_perm, E->stream));
         E->steps_since_rebuild = 0;
       }
     }
+    return GTE_OK;
+  };
+  if (!fused) {
+    // same results, one launch per step
+    for (int32_t k = 0; k < n_steps; ++k) TRY(step_row(k));
+  } else if (!b->obs) {
+    // Backtest: no observation is kept but the last one.  n_steps - 1 steps of pure state machine
+    // from registers (gte_rollout_state_kernel), then the last step as an ordinary launch, which
+    // also produces the observation and the terminal list.
+    if (n_steps > 1) {
+      TRY(count_steps(n_steps - 1));
+      gte::RolloutArgs r = {actions, n_steps - 1, nullptr, b->reward, b->reward64, b->terminated,
+                            b->truncated, b->valuation, 0};
+      // identity order: with no window to gather, the L2-affinity order would only scatter the
+      // per-env loads and stores (actions, rewards, flags) that are coalesced in env order
+      Params ps = E->p;
+      ps.perm = nullptr;
+      // envs per wavefront: full waves once every SIMD has one (65 536 envs: 5.8 us per step
+      // with 64, 6.0 with 32, 9.2 with 16 — throughput of the scattered record / ring stores);
+      // small batches are a latency chain and two half-filled waves overlap better (4 096 envs:
+      // 3.5 us with 32, 3.9 with 64) — profiles/r02_state_epw.log
+      const int sepw = (E->p.N >= 64 * 1024) ? 64 : 32;
+      const hipError_t le = gte::launch_rollout_state(ps, r, n_steps - 1, sepw, E->stream);
+      if (le != hipSuccess) return fail(GTE_ERR_HIP, "rollout launch: %s", hipGetErrorString(le));
+    }
+    TRY(step_row(n_steps - 1));
+  } else {
+    TRY(count_steps(n_steps));
     Params p = E->p;
-    if (E->rollout_epw == 0) {
-      // The rollout kernel is a long-running loop: a workgroup that is not resident from the
-      // start runs all K steps after the others have finished.  It needs more registers than
-      // the step kernel (4 workgroups per CU instead of 5), so it gets its own workgroup size,
-      // the smallest that keeps every workgroup resident (the processing order `perm` does not
-      // depend on the workgroup size).
-      E->rollout_epw = p.epw;
+    // Window-resident kernel (gte_rollout.hip): each env's W-1 older rows stay in LDS for the
+    // whole launch.  Geometry: E envs per workgroup such that (a) the newest rows fit the owner
+    // threads, (b) as many envs as possible are resident per CU and (c) the workgroups fill a
+    // whole number of rounds (each workgroup runs all K steps, so a part-filled last round costs
+    // a full one): minimise rounds x max(phase A chain, the CU's observation bytes per step).
+    const int nt = E->cfg.nontemporal_obs;
+    if (E->resident_epb[nt] == 0) {
+      E->resident_epb[nt] = -1;
       hipDeviceProp_t prop;
-      if (cfg_is_auto_epw(E) && hipGetDeviceProperties(&prop, E->cfg.device) == hipSuccess) {
-        for (int e = 1; e <= 16; ++e) {
-          Params q = p;
-          q.epw = e;
-          if ((int64_t)e * p.W * p.Fobs / 4 < 64) continue;
-          const int per_cu = gte::rollout_blocks_per_cu(q, E->cfg.nontemporal_obs);
-          const int64_t wgs = ((int64_t)p.N + 4 * e - 1) / (4 * e);
-          if (per_cu > 0 && wgs <= (int64_t)per_cu * prop.multiProcessorCount) { E->rollout_epw = e; break; }
-          if (e == 16) E->rollout_epw = 16;  // more envs than one round holds: biggest workgroups
+      const int64_t FV = p.Fobs / 4;
+      if (p.W >= 2 && !(E->cfg.kernel_variant & 256) &&
+          hipGetDeviceProperties(&prop, E->cfg.device) == hipSuccess) {
+        double best = 0.0;
+        for (int e = 64; e >= 1; --e) {
+          if ((int64_t)e * FV > 2 * 192) continue;  // RES_NEW * RES_OWNERS newest-row vectors
+          if (gte::resident_lds_bytes(p, e) > (size_t)160 * 1024) continue;
+          const int per_cu = gte::resident_blocks_per_cu(p, e, nt);
+          if (per_cu <= 0) continue;
+          const int64_t slots = (int64_t)per_cu * prop.multiProcessorCount;
+          const int64_t wgs = ((int64_t)p.N + e - 1) / e;
+          const int64_t rounds = (wgs + slots - 1) / slots;
+          const double live = (double)(wgs < slots ? (wgs + prop.multiProcessorCount - 1) / prop.multiProcessorCount
+                                                   : per_cu);  // workgroups sharing a CU
+          const double us_bw = live * e * (double)p.W * p.Fobs * 4.0 / 22.0e3;  // ~5.6 TB/s over 256 CUs
+          const double cost = (double)rounds * (us_bw > 3.0 ? us_bw : 3.0);
+          if (getenv("GTE_DEBUG_GEOMETRY"))
+            fprintf(stderr, "[gte] resident rollout, %2d envs/workgroup: LDS %6zu B, %d workgroups/CU, "
+                            "%lld workgroups, %lld round(s), cost %.1f\n", e, gte::resident_lds_bytes(p, e),
+                    per_cu, (long long)wgs, (long long)rounds, cost);
+          if (best == 0.0 || cost < best * 0.999) { best = cost; E->resident_epb[nt] = e; }
         }
       }
     }
-    p.epw = E->rollout_epw;
-    const int r_blocks = (int)((((int64_t)p.N + p.epw - 1) / p.epw + 3) / 4);
     E->term_slot ^= 1;
     p.term_count = E->term_base + E->term_slot;
     p.term_count_next = E->term_base + (E->term_slot ^ 1);
-    gte::RolloutArgs r = {actions, n_steps, b->obs, b->reward, b->reward64, b->terminated,
-                          b->truncated, b->valuation};
-    const hipError_t le = gte::launch_rollout(p, r, E->cfg.nontemporal_obs, r_blocks, E->threads,
-                                              E->stream);
-    if (le != hipSuccess) return fail(GTE_ERR_HIP, "rollout launch: %s", hipGetErrorString(le));
+    if (E->resident_epb[nt] > 0) {
+      // identity processing order: the L2-affinity order exists for the table reads of the
+      // per-step gather; here one row per env and step is read, and consecutive envs make each
+      // workgroup's observation stores one contiguous run (measured 29.3 vs 33.0 us per step)
+      p.perm = nullptr;
+      gte::RolloutArgs r = {actions, n_steps, b->obs, b->reward, b->reward64, b->terminated,
+                            b->truncated, b->valuation, E->resident_epb[nt]};
+      const hipError_t le = gte::launch_rollout_resident(p, r, nt, E->stream);
+      if (le != hipSuccess) return fail(GTE_ERR_HIP, "rollout launch: %s", hipGetErrorString(le));
+    } else {
+      if (E->rollout_epw == 0) {
+        // The gather-per-step rollout kernel is a long-running loop: a workgroup that is not
+        // resident from the start runs all K steps after the others have finished.  It needs more
+        // registers than the step kernel, so it gets its own workgroup size, the smallest that
+        // keeps every workgroup resident.
+        E->rollout_epw = p.epw;
+        hipDeviceProp_t prop;
+        if (cfg_is_auto_epw(E) && hipGetDeviceProperties(&prop, E->cfg.device) == hipSuccess) {
+          for (int e = 1; e <= 16; ++e) {
+            Params q = p;
+            q.epw = e;
+            if ((int64_t)e * p.W * p.Fobs / 4 < 64) continue;
+            const int per_cu = gte::rollout_blocks_per_cu(q, E->cfg.nontemporal_obs);
+            const int64_t wgs = ((int64_t)p.N + 4 * e - 1) / (4 * e);
+            if (per_cu > 0 && wgs <= (int64_t)per_cu * prop.multiProcessorCount) { E->rollout_epw = e; break; }
+            if (e == 16) E->rollout_epw = 16;  // more envs than one round holds: biggest workgroups
+          }
+        }
+      }
+      p.epw = E->rollout_epw;
+      const int r_blocks = (int)((((int64_t)p.N + p.epw - 1) / p.epw + 3) / 4);
+      gte::RolloutArgs r = {actions, n_steps, b->obs, b->reward, b->reward64, b->terminated,
+                            b->truncated, b->valuation, 0};
+      const hipError_t le = gte::launch_rollout(p, r, E->cfg.nontemporal_obs, r_blocks, E->threads,
+                                                E->stream);
+      if (le != hipSuccess) return fail(GTE_ERR_HIP, "rollout launch: %s", hipGetErrorString(le));
+    }
   }
   // the env's own return buffers describe the last step
   const size_t last = (size_t)(n_steps - 1) * N;
@@ -759,39 +851,78 @@ int gte_get_log(gte_env* E, gte_log_view* out) {
   out->dataset_index = E->log.dsi; out->portfolio_valuation = E->log.pv;
   out->real_position = E->log.realpos; out->reward = E->log.reward; out->flags = E->log.flags;
   out->rows = E->log_rows; out->L = E->cfg.log_steps; out->N = E->p.N;
+  out->asset = E->log.asset; out->fiat = E->log.fiat;
+  out->interest_asset = E->log.ia; out->interest_fiat = E->log.ifi;
+  return GTE_OK;
+}
+
+// rows first .. first+n-1 (mod L) of ONE env, oldest first: at most two strided 2-D copies per array
+static int pull_log_column(gte_env* E, int32_t env_id, int64_t first, int32_t n, void* host,
+                           const void* dev, size_t elem) {
+  if (!host) return GTE_OK;
+  const int N = E->p.N, L = E->cfg.log_steps;
+  const int64_t run1 = (first + n <= L) ? n : (L - first);
+  HIPCHK(hipMemcpy2D(host, elem, (const char*)dev + ((size_t)first * N + env_id) * elem,
+                     (size_t)N * elem, elem, (size_t)run1, hipMemcpyDeviceToHost));
+  if (run1 < n)
+    HIPCHK(hipMemcpy2D((char*)host + run1 * elem, elem, (const char*)dev + (size_t)env_id * elem,
+                       (size_t)N * elem, elem, (size_t)(n - run1), hipMemcpyDeviceToHost));
+  return GTE_OK;
+}
+
+static int log_window(gte_env* E, int32_t env_id, int32_t* n, int32_t* n_out, int64_t* first) {
+  if (!E || !n_out) return fail(GTE_ERR_INVALID, "NULL argument");
+  if (E->cfg.log_steps <= 0) return fail(GTE_ERR_STATE, "created with log_steps = 0");
+  const int N = E->p.N, L = E->cfg.log_steps;
+  if (env_id < 0 || env_id >= N) return fail(GTE_ERR_INVALID, "env_id out of range");
+  const int64_t have = E->log_rows < L ? E->log_rows : L;
+  if (*n > have) *n = (int32_t)have;
+  if (*n < 0) *n = 0;
+  *n_out = *n;
+  *first = *n ? (E->log_rows - *n) % L : 0;
+  if (*n) {
+    HIPCHK(hipSetDevice(E->cfg.device));
+    HIPCHK(hipStreamSynchronize(E->stream));
+  }
   return GTE_OK;
 }
 
 int gte_read_log(gte_env* E, int32_t env_id, int32_t n, int32_t* idx, int32_t* step,
                  int32_t* position_index, int32_t* dataset_index, double* portfolio_valuation,
                  double* real_position, double* reward, uint8_t* flags, int32_t* n_out) {
-  if (!E || !n_out) return fail(GTE_ERR_INVALID, "NULL argument");
-  if (E->cfg.log_steps <= 0) return fail(GTE_ERR_STATE, "created with log_steps = 0");
-  const int N = E->p.N, L = E->cfg.log_steps;
-  if (env_id < 0 || env_id >= N) return fail(GTE_ERR_INVALID, "env_id out of range");
-  int64_t have = E->log_rows < L ? E->log_rows : L;
-  if (n > have) n = (int32_t)have;
-  if (n < 0) n = 0;
-  *n_out = n;
+  int64_t first = 0;
+  TRY(log_window(E, env_id, &n, n_out, &first));
   if (n == 0) return GTE_OK;
-  HIPCHK(hipSetDevice(E->cfg.device));
-  HIPCHK(hipStreamSynchronize(E->stream));
-  // rows first .. first+n-1 (mod L), oldest first: at most two strided 2-D copies per array
-  const int64_t first = (E->log_rows - n) % L;
-  auto pull = [&](void* host, const void* dev, size_t elem) -> int {
-    if (!host) return GTE_OK;
-    const int64_t run1 = (first + n <= L) ? n : (L - first);
-    HIPCHK(hipMemcpy2D(host, elem, (const char*)dev + ((size_t)first * N + env_id) * elem,
-                       (size_t)N * elem, elem, (size_t)run1, hipMemcpyDeviceToHost));
-    if (run1 < n)
-      HIPCHK(hipMemcpy2D((char*)host + run1 * elem, elem, (const char*)dev + (size_t)env_id * elem,
-                         (size_t)N * elem, elem, (size_t)(n - run1), hipMemcpyDeviceToHost));
-    return GTE_OK;
-  };
-  TRY(pull(idx, E->log.idx, 4)); TRY(pull(step, E->log.step, 4));
-  TRY(pull(position_index, E->log.pos, 4)); TRY(pull(dataset_index, E->log.dsi, 4));
-  TRY(pull(portfolio_valuation, E->log.pv, 8)); TRY(pull(real_position, E->log.realpos, 8));
-  TRY(pull(reward, E->log.reward, 8)); TRY(pull(flags, E->log.flags, 1));
+  TRY(pull_log_column(E, env_id, first, n, idx, E->log.idx, 4));
+  TRY(pull_log_column(E, env_id, first, n, step, E->log.step, 4));
+  TRY(pull_log_column(E, env_id, first, n, position_index, E->log.pos, 4));
+  TRY(pull_log_column(E, env_id, first, n, dataset_index, E->log.dsi, 4));
+  TRY(pull_log_column(E, env_id, first, n, portfolio_valuation, E->log.pv, 8));
+  TRY(pull_log_column(E, env_id, first, n, real_position, E->log.realpos, 8));
+  TRY(pull_log_column(E, env_id, first, n, reward, E->log.reward, 8));
+  TRY(pull_log_column(E, env_id, first, n, flags, E->log.flags, 1));
+  return GTE_OK;
+}
+
+int gte_read_log_portfolio(gte_env* E, int32_t env_id, int32_t n, double* asset, double* fiat,
+                           double* interest_asset, double* interest_fiat, int32_t* n_out) {
+  int64_t first = 0;
+  TRY(log_window(E, env_id, &n, n_out, &first));
+  if (n == 0) return GTE_OK;
+  TRY(pull_log_column(E, env_id, first, n, asset, E->log.asset, 8));
+  TRY(pull_log_column(E, env_id, first, n, fiat, E->log.fiat, 8));
+  TRY(pull_log_column(E, env_id, first, n, interest_asset, E->log.ia, 8));
+  TRY(pull_log_column(E, env_id, first, n, interest_fiat, E->log.ifi, 8));
+  return GTE_OK;
+}
+
+int gte_set_log_reward(gte_env* E, const double* reward_device) {
+  if (!E || !reward_device) return fail(GTE_ERR_INVALID, "NULL argument");
+  if (E->cfg.log_steps <= 0) return fail(GTE_ERR_STATE, "created with log_steps = 0");
+  if (E->log_rows <= 0) return fail(GTE_ERR_STATE, "the log is empty");
+  const int64_t row = (E->log_rows - 1) % E->cfg.log_steps;
+  HIPCHK(hipMemcpyAsync(E->log.reward + row * (int64_t)E->p.N, reward_device, sizeof(double) * (size_t)E->p.N,
+                        hipMemcpyDeviceToDevice, E->stream));
   return GTE_OK;
 }
 
@@ -897,6 +1028,30 @@ int gte_get_state(gte_env* E, gte_state_view* out) {
   HIPCHK(hipSetDevice(E->cfg.device));
   HIPCHK(gte::launch_extract_state(E->p.rec, E->p.N, E->soa, E->stream));
   const gte::StateSoA& o = E->soa;
+  out->idx = o.idx; out->step = o.step; out->position_index = o.pos;
+  out->dataset_index = o.dsi; out->start_idx = o.start; out->episode = o.episode;
+  out->needs_reset = o.needs_reset; out->asset = o.asset; out->fiat = o.fiat;
+  out->interest_asset = o.ia; out->interest_fiat = o.ifi;
+  out->portfolio_valuation = o.pv; out->real_position = o.realpos;
+  return GTE_OK;
+}
+
+int gte_set_dynamic_features(gte_env* E, const float* values_device, uint32_t mask) {
+  if (!E || !values_device) return fail(GTE_ERR_INVALID, "NULL argument");
+  if (!E->was_reset) return fail(GTE_ERR_STATE, "gte_set_dynamic_features before gte_reset");
+  if (E->p.nd <= 0 || (mask >> E->p.nd) != 0u)
+    return fail(GTE_ERR_INVALID, "mask 0x%x names features beyond n_dyn = %d", mask, E->p.nd);
+  HIPCHK(hipSetDevice(E->cfg.device));
+  HIPCHK(gte::launch_set_dynamic(E->p, values_device, mask, E->stream));
+  return GTE_OK;
+}
+
+int gte_get_final_state(gte_env* E, gte_state_view* out) {
+  if (!E || !out) return fail(GTE_ERR_INVALID, "NULL argument");
+  if (!E->p.final_rec) return fail(GTE_ERR_STATE, "created without final_obs");
+  HIPCHK(hipSetDevice(E->cfg.device));
+  HIPCHK(gte::launch_extract_state(E->p.final_rec, E->p.N, E->fsoa, E->stream));
+  const gte::StateSoA& o = E->fsoa;
   out->idx = o.idx; out->step = o.step; out->position_index = o.pos;
   out->dataset_index = o.dsi; out->start_idx = o.start; out->episode = o.episode;
   out->needs_reset = o.needs_reset; out->asset = o.asset; out->fiat = o.fiat;

@@ -12,6 +12,7 @@ struct LogArrays {
   int32_t *idx, *step, *pos, *dsi;
   double *pv, *realpos, *reward;
   uint8_t* flags;
+  double *asset, *fiat, *ia, *ifi;  // Portfolio state: get_portfolio_distribution (portfolio.py:49-57)
 };
 
 __global__ void gte_log_kernel(const EnvRec* rec, const double* reward64, const uint8_t* term,
@@ -22,6 +23,7 @@ __global__ void gte_log_kernel(const EnvRec* rec, const double* reward64, const 
   const int64_t k = row_base + e;
   o.idx[k] = r.idx; o.step[k] = r.step; o.pos[k] = r.pos; o.dsi[k] = r.dsi;
   o.pv[k] = r.pv; o.realpos[k] = r.realpos; o.reward[k] = reward64[e];
+  o.asset[k] = r.asset; o.fiat[k] = r.fiat; o.ia[k] = r.ia; o.ifi[k] = r.ifi;
   o.flags[k] = (uint8_t)((term[e] ? 1 : 0) | (trunc[e] ? 2 : 0));
 }
 
@@ -30,6 +32,31 @@ hipError_t launch_log(const EnvRec* rec, const double* reward64, const uint8_t* 
                       hipStream_t stream) {
   hipLaunchKernelGGL(gte_log_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, rec, reward64, term,
                      trunc, n, row_base, o);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Dynamic features computed OUTSIDE the step kernel (a user's Python callable evaluated
+// vectorised over the batch, reference environments.py:152-154): overwrite feature i (bit i of
+// `mask`) of the CURRENT row of every env — in the env's dynamic store, from where later windows
+// read it, and in the observation the last launch produced.
+__global__ void gte_set_dynamic_kernel(const Params p, const float* values, uint32_t mask) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.N) return;
+  const int32_t idx = p.rec[e].idx;
+  const int64_t slot = p.persist ? (int64_t)idx : (int64_t)(idx % p.W);
+  float* ring = p.ring + ((int64_t)e * p.depth + slot) * p.nd;
+  float* row = p.obs + ((int64_t)e * p.W + (p.W - 1)) * p.Fobs + p.Fs;
+  for (int i = 0; i < p.nd; ++i)
+    if (mask & (1u << i)) {
+      const float v = values[(int64_t)e * p.nd + i];
+      ring[i] = v;
+      row[i] = v;
+    }
+}
+
+hipError_t launch_set_dynamic(const Params& p, const float* values, uint32_t mask, hipStream_t stream) {
+  hipLaunchKernelGGL(gte_set_dynamic_kernel, dim3((p.N + 255) / 256), dim3(256), 0, stream, p, values, mask);
   return hipGetLastError();
 }
 

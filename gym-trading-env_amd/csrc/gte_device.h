@@ -57,6 +57,8 @@ struct Params {
   uint8_t* lo_persist;  // u8  [N, P]
   // --- outputs
   float* final_obs;  // f32 [N, W, Fobs] or null: terminal observations (same-step mode)
+  EnvRec* final_rec; // [N] or null: the record of env e as it was when its episode ended (same-step
+                     // mode with final_obs: what `final_info` reports; gte_get_final_state)
   float* obs;
   float* reward;
   double* reward64;

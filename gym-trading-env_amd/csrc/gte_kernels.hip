@@ -78,8 +78,7 @@ __device__ inline void load_state(const Params& p, int e, EnvRegs& s) {
 }
 
 // start and lo_n are written where they change (do_reset, fill_limit_orders)
-__device__ inline void store_state(const Params& p, int e, const EnvRegs& s) {
-  EnvRec* r = &p.rec[e];
+__device__ inline void store_state_at(EnvRec* r, const EnvRegs& s) {
   *reinterpret_cast<int4*>(&r->idx) = make_int4(s.idx, s.step, s.pos, s.dsi);
   r->needs_reset = s.needs_reset;
   double2* d = reinterpret_cast<double2*>(&r->asset);
@@ -87,6 +86,7 @@ __device__ inline void store_state(const Params& p, int e, const EnvRegs& s) {
   d[1] = make_double2(s.q.ia, s.q.ifi);
   d[2] = make_double2(s.pv, s.realpos);
 }
+__device__ inline void store_state(const Params& p, int e, const EnvRegs& s) { store_state_at(&p.rec[e], s); }
 
 // MultiDatasetTradingEnv.next_dataset, environments.py:380-391
 __device__ inline void next_dataset(const Params& p, int e, int32_t inj_ds, EnvRegs& s,
@@ -244,10 +244,14 @@ __device__ inline void make_job(const Params& p, int e, const EnvRegs& s, bool f
 
 // compact: add the envs whose episode ended to the terminal list (off for the inner steps
 // of a fused rollout, which keeps per-step flags instead); pv_out: the valuation after the step.
+// carried: the env's registers live across calls (the fused rollout keeps them there for all K
+// steps: no record load per step; the record is still written through); action_in: the action
+// was loaded ahead of time.  Both are nullptr — and fold away — in the per-step kernels.
 template <int MODE>
 __device__ inline void phase_a(const Params& p, int e, bool active, int lane, ObsJob& job,
                                FinalJob* fin = nullptr, bool compact = true,
-                               double* pv_out = nullptr) {
+                               double* pv_out = nullptr, EnvRegs* carried = nullptr,
+                               const int32_t* action_in = nullptr) {
   if (fin) fin->flags = 0;
   job.src = nullptr; job.slot0 = 0; job.n_zero = 0; job.idx = 0; job.flags = 0;
 #pragma unroll
@@ -274,9 +278,10 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
 
   // MODE_STEP — TradingEnv.step, environments.py:233-272
   if (active) {
-    EnvRegs s;
-    load_state(p, e, s);
-    int32_t action = p.actions[e];
+    EnvRegs s_own;
+    EnvRegs& s = carried ? *carried : s_own;
+    if (!carried) load_state(p, e, s);
+    int32_t action = action_in ? *action_in : p.actions[e];
     GTE_STAMP(2);  // record + action arrived
     // positions[position_index] raises IndexError in the reference (:234); a device-side
     // action cannot raise, so an out-of-range index is treated as None (hold), never read
@@ -341,6 +346,10 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
       if (ended && p.autoreset == GTE_AUTORESET_SAME_STEP) {
         // the reference's step() runs _get_obs (:272) before any wrapper resets the env:
         // write the terminal row's dynamic features, remember the terminal window
+        if (p.final_rec) {  // what the wrapper's `final_info` reports (state before the reset)
+          store_state_at(&p.final_rec[e], s);
+          p.final_rec[e].start = s.start;
+        }
         ObsJob term;
         make_job(p, e, s, false, term);
         int32_t qi, qp, qd;

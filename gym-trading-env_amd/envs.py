@@ -12,8 +12,8 @@ legacy RNG with the reference's calls in the reference's order
 
 This N=1 form is interpreter- and PCIe-bound like the reference; throughput comes from
 `BatchedTradingEnv`.  Differences, all documented in DESIGN.md: dynamic features and
-device rewards are limited to the built-ins (custom `reward_function` callables run on
-the host over the History).
+device rewards are limited to the built-ins; any other `reward_function` /
+`dynamic_feature_functions` callable — whatever its name — runs on the host over the History.
 """
 from __future__ import annotations
 
@@ -26,7 +26,9 @@ import numpy as np
 
 from . import _abi, spaces, staging
 from .batched import BatchedTradingEnv
-from .config import _REWARD_BY_NAME, resolve_dynamic_features
+from .config import HOST_CALLABLE, resolve_dynamic_features, resolve_reward
+from .defaults import (basic_reward_function, dynamic_feature_last_position_taken,  # noqa: F401
+                       dynamic_feature_real_position)
 from .history import History
 
 try:  # soft dependency
@@ -39,19 +41,6 @@ except Exception:  # gymnasium absent: same reset(seed=) contract, nothing else 
         def reset(self, seed=None, options=None):
             if seed is not None:
                 self.np_random = np.random.default_rng(seed)
-
-
-def basic_reward_function(history: History):
-    """ln(pv_t / pv_{t-1}) — recognised by name and computed on the device."""
-    return np.log(history["portfolio_valuation", -1] / history["portfolio_valuation", -2])
-
-
-def dynamic_feature_last_position_taken(history):
-    return history["position", -1]
-
-
-def dynamic_feature_real_position(history):
-    return history["real_position", -1]
 
 
 class TradingEnv(_EnvBase):
@@ -83,18 +72,17 @@ class TradingEnv(_EnvBase):
         assert render_mode is None or render_mode in self.metadata["render_modes"]
         self.render_mode = render_mode
         self._device = device
-        # dynamic features the device knows run there; any other callable makes ALL of them
-        # host-side columns, evaluated over the History like the reference does (:153-154)
-        try:
-            resolve_dynamic_features(dynamic_feature_functions)
-            self._host_dyn = False
-        except NotImplementedError:
-            if not all(callable(f) for f in dynamic_feature_functions):
-                raise
-            self._host_dyn = True
-        rname = getattr(reward_function, "__name__", reward_function)
-        # a custom reward callable is evaluated on the host over the History (:265-267)
-        self._host_reward = not (isinstance(reward_function, tuple) or rname in _REWARD_BY_NAME)
+        # The device computes this package's own default objects (recognised by IDENTITY, never
+        # by name) and the string / tuple specs.  Any other callable is the user's code: one such
+        # dynamic feature makes ALL of them host-side columns, evaluated over the History like the
+        # reference does (:153-154) ...
+        kinds = resolve_dynamic_features(dynamic_feature_functions)
+        self._host_dyn = HOST_CALLABLE in kinds
+        if self._host_dyn and not all(callable(f) for f in dynamic_feature_functions):
+            raise TypeError("with a custom dynamic feature every entry of dynamic_feature_functions "
+                            "must be a callable")
+        # ... and a custom reward callable is evaluated on the host over the History (:265-267)
+        self._host_reward = resolve_reward(reward_function)[0] == HOST_CALLABLE
         self._batch = None
         self._set_df(df)
         self.action_space = spaces.Discrete(len(positions))

@@ -37,6 +37,17 @@ class History:
         self._cols = {}
         self.size = 0
 
+    @classmethod
+    def from_columns(cls, columns: dict):
+        """A History holding whole columns at once ({flattened column name: sequence}); what the
+        batch builds from the device trajectory log instead of one add() per row."""
+        h = cls(max_size=max(1, max((len(v) for v in columns.values()), default=1)))
+        h.columns = list(columns)
+        h.width = len(h.columns)
+        h._cols = {c: list(v) for c, v in columns.items()}
+        h.size = len(next(iter(h._cols.values()))) if h._cols else 0
+        return h
+
     def set(self, **kwargs):
         self.columns, values = _flatten(kwargs)
         self.width = len(self.columns)

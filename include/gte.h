@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GTE_ABI_VERSION 1
+#define GTE_ABI_VERSION 2
 #define GTE_MAX_POSITIONS 32
 #define GTE_MAX_DYN 4
 
@@ -122,7 +122,9 @@ typedef struct gte_config {
                                64 = launch the shared-TU instantiation of the hot
                                kernel instead of the isolated one (gte_hot.hip),
                                128 = gte_rollout runs as one launch per step even
-                               where the fused kernel applies                      */
+                               where the fused kernels apply, 256 = gte_rollout uses
+                               the gather-per-step fused kernel instead of the
+                               window-resident one                                 */
   int32_t debug_flags;      /* timing ablations only (results become wrong):
                                1 = skip the observation gather, 2 = skip the
                                dynamic-column patch, 8 = skip the window loads
@@ -230,6 +232,14 @@ int gte_step(gte_env* env, const int32_t* actions, int32_t actions_on_device);
 int gte_add_limit_orders(gte_env* env, const int32_t* pos_index, const double* limit,
                          const uint8_t* persistent);
 
+/* Dynamic features the device does not compute (a user's Python callable evaluated vectorised
+ * over the batch, environments.py:152-154 `_obs_array[_idx, F_s + i] = f(history)`): overwrite
+ * feature i, for every bit i of `mask`, of the CURRENT row of every env with values_device
+ * (DEVICE f32 [N, n_dyn]) — in the env's dynamic-feature store, from where the windows of later
+ * steps read it, and in the observation the last gte_step / gte_reset produced.  Stream-ordered;
+ * call it after every step and reset. */
+int gte_set_dynamic_features(gte_env* env, const float* values_device, uint32_t mask);
+
 /* Device trajectory log (gte_config.log_steps = L): after every gte_reset / gte_step a small
  * kernel appends one row per env.  Row r of env e lives at index (r % L) * N + e of each
  * array; `rows` counts the rows written so far (the newest is rows - 1).  An episode of
@@ -246,6 +256,10 @@ typedef struct gte_log_view {
   int64_t  rows;            /* rows written since gte_create                      */
   int32_t  L;
   int32_t  N;
+  double*  asset;           /* f64 [L, N] Portfolio.asset / fiat / interest_asset /  */
+  double*  fiat;            /*   interest_fiat: what `portfolio_distribution_*`      */
+  double*  interest_asset;  /*   derives from (portfolio.py:49-57, History columns   */
+  double*  interest_fiat;   /*   environments.py:262)                                */
 } gte_log_view;
 int gte_get_log(gte_env* env, gte_log_view* out);
 /* the last `n` (<= L) rows of ONE env, oldest first, into host arrays of length n (any may
@@ -253,6 +267,13 @@ int gte_get_log(gte_env* env, gte_log_view* out);
 int gte_read_log(gte_env* env, int32_t env_id, int32_t n, int32_t* idx, int32_t* step,
                  int32_t* position_index, int32_t* dataset_index, double* portfolio_valuation,
                  double* real_position, double* reward, uint8_t* flags, int32_t* n_out);
+/* the Portfolio columns of the same rows (asset, fiat, interest_asset, interest_fiat) */
+int gte_read_log_portfolio(gte_env* env, int32_t env_id, int32_t n, double* asset, double* fiat,
+                           double* interest_asset, double* interest_fiat, int32_t* n_out);
+/* Overwrite the `reward` column of the NEWEST log row with device values f64 [N] — what the
+ * reference does with a custom reward_function: `historical_info["reward", -1] = reward`
+ * (environments.py:265-267).  Stream-ordered. */
+int gte_set_log_reward(gte_env* env, const double* reward_device);
 
 /* Per-step results of gte_rollout, all device pointers, all optional (NULL = not kept).
  * Row k holds what the k-th gte_step of the sequence would have produced. */
@@ -279,6 +300,13 @@ int gte_rollout(gte_env* env, const int32_t* actions, int32_t n_steps, const gte
 
 /* Where the results of the last gte_step / gte_reset live (device pointers). */
 int gte_get_outputs(gte_env* env, gte_outputs* out);
+/* Same-step auto-reset with gte_config.final_obs: struct-of-arrays snapshot (device pointers,
+ * extracted like gte_get_state) of every env's record AS IT WAS WHEN ITS LAST EPISODE ENDED —
+ * the state `TradingEnv.step` reported in `info` before the wrapper reset the env
+ * (Gymnasium `final_info`).  Row e is meaningful for the envs listed in term_ids after a step.
+ * `episode` / `needs_reset` of the view are not meaningful here. */
+int gte_get_final_state(gte_env* env, gte_state_view* out);
+
 /* Snapshot of the per-env state as struct-of-arrays device buffers.  Internally the
  * state is one 128-byte record per env; this call enqueues a small extraction
  * kernel on the env's stream, so the views reflect every launch enqueued before

@@ -147,7 +147,7 @@ def test_tradingenv_metrics_history_and_errors(tmp_path):
     assert {"open", "close", "portfolio_valuation", "position", "reward"} <= set(saved.columns)
     with pytest.raises(AssertionError):
         TradingEnv(df=df, positions=[0, 1], initial_position=0.5)
-    with pytest.raises(NotImplementedError):  # names the device does not know, not callable
+    with pytest.raises(ValueError):  # a spec the device does not know, not callable
         TradingEnv(df=df, dynamic_feature_functions=["no_such_feature"])
     const = TradingEnv(df=df, dynamic_feature_functions=[lambda h: 1.0], verbose=0)  # host-side
     obs, _ = const.reset()
@@ -391,8 +391,13 @@ def test_custom_dynamic_feature_callables_run_on_the_host():
     assert custom._trace[-1][-2, 4] == np.float32(h["portfolio_valuation", -2] / 1000.0)
     builtin.close()
     custom.close()
-    with pytest.raises(NotImplementedError):  # the batch cannot call Python per env
-        gte.BatchedTradingEnv(df, num_envs=4, dynamic_feature_functions=[valuation_ratio])
+    # the batch takes the same callable: evaluated once per step for all envs (vectorised over a
+    # BatchedHistory, tests/test_gpu_vector_api.py)
+    batch = gte.BatchedTradingEnv(df, num_envs=4, dynamic_feature_functions=[valuation_ratio],
+                                  positions=[-1, 0, 1])
+    obs, _ = batch.reset()
+    assert obs.shape == (4, 3) and (obs.cpu().numpy()[:, -1] == 1.0).all()
+    batch.close()
 
 
 def test_copy_false_returns_views_of_the_staging_buffer():

