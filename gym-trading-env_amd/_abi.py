@@ -13,6 +13,7 @@ import os
 GTE_ABI_VERSION = 2
 GTE_MAX_POSITIONS = 32
 GTE_MAX_DYN = 4
+GTE_COMM_ID_BYTES = 128
 
 GTE_OK = 0
 GTE_ERR_INVALID = -1
@@ -196,6 +197,14 @@ SYMBOLS = {
                                      _P(C.c_void_p), _P(C.c_void_p)]),
     "gte_rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, _P(GteRolloutBufs)]),
     "gte_bind_returns": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gte_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "gte_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "gte_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]),
+    "gte_allgather_returns": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, _P(C.c_void_p)]),
+    "gte_allgather_obs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "gte_comm_wait": (C.c_int, [C.c_void_p]),
+    "gte_comm_synchronize": (C.c_int, [C.c_void_p]),
+    "gte_comm_destroy": (C.c_int, [C.c_void_p]),
     "gte_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gte_use_own_stream": (C.c_int, [C.c_void_p]),
     "gte_synchronize": (C.c_int, [C.c_void_p]),

@@ -58,6 +58,12 @@ hipError_t launch_log(const EnvRec* rec, const double* reward64, const uint8_t* 
 hipError_t launch_snapshot(const EnvRec* rec, const double* reward64, const uint8_t* term,
                            const uint8_t* trunc, const float* obs, int64_t obs_elems, int first,
                            int count, void* dst, float* dst_obs, hipStream_t stream);
+const char* rccl_load();
+const char* rccl_error(int code);
+int rccl_unique_id(uint8_t* out128);
+int rccl_comm_init(void** comm, const uint8_t* id128, int rank, int world);
+int rccl_allgather_bytes(void* comm, const void* src, void* dst, size_t bytes, hipStream_t stream);
+int rccl_comm_destroy(void* comm);
 hipError_t launch_set_dynamic(const Params& p, const float* values, uint32_t mask, hipStream_t stream);
 hipError_t launch_affinity_rebuild(const Params& p, int32_t* bins, int n_bins_per_ds,
                                    const int32_t* slot_of_rank, int32_t* perm_out,
@@ -131,6 +137,12 @@ struct gte_env {
                                     // store policy (0 = not chosen yet, -1 = shape not covered)
   int hot_per_cu = 0;      // resident workgroups per CU the geometry was sized for (0 = n/a)
   bool store_auto = false; // the observation store policy was chosen here (cfg said 3)
+  // multi-GPU return exchange (gte_comm.hip): one RCCL communicator per env
+  void* comm = nullptr;
+  int comm_rank = 0, comm_world = 0;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t comm_ready = nullptr, comm_done = nullptr;
+  uint8_t* gathered_returns = nullptr;  // u8 [world, 6N], library-owned destination
   void* h_snap = nullptr;  // pinned host memory for gte_read_envs: snapshots, then observations
   size_t h_snap_bytes = 0;
   bool view_reads = false; // gte_read_envs_view has been used: the buffer is kept at full size
@@ -292,8 +304,15 @@ int gte_create(const gte_config* cfg, gte_env** out) {
     chk(dev_alloc(E, &E->fsoa.ia, N)); chk(dev_alloc(E, &E->fsoa.ifi, N));
     chk(dev_alloc(E, &E->fsoa.pv, N)); chk(dev_alloc(E, &E->fsoa.realpos, N));
   }
-  chk(dev_alloc(E, &E->owned.reward, N)); chk(dev_alloc(E, &E->owned.reward64, N));
-  chk(dev_alloc(E, &E->owned.terminated, N)); chk(dev_alloc(E, &E->owned.truncated, N));
+  {  // reward f32 [N] | terminated u8 [N] | truncated u8 [N] in ONE buffer of 6N bytes: the
+     // layout a sharded run all-gathers as it is (gte_allgather_returns), no packing kernel
+    uint8_t* packed = nullptr;
+    chk(dev_alloc(E, &packed, 6 * N + 16));
+    E->owned.reward = (float*)packed;
+    E->owned.terminated = packed ? packed + 4 * N : nullptr;
+    E->owned.truncated = packed ? packed + 5 * N : nullptr;
+  }
+  chk(dev_alloc(E, &E->owned.reward64, N));
   chk(dev_alloc(E, &E->owned.term_count, 2)); chk(dev_alloc(E, &E->owned.term_ids, N));
   chk(dev_alloc(E, &E->d_actions, N)); chk(dev_alloc(E, &E->d_mask, N));
   chk(dev_alloc(E, &E->d_inj_idx, N)); chk(dev_alloc(E, &E->d_inj_pos, N));
@@ -399,7 +418,18 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   // L2-affinity order: only worth it when every XCD gets several workgroups and the
   // windows are big enough to be bandwidth-bound
   {
-    const int period = cfg->affinity_period == 0 ? 128 : cfg->affinity_period;
+    // Default re-sort period: the order decays as envs jump to new start rows, i.e. with the
+    // reset rate, about 1 / max_episode_duration of the envs per step once the episodes are out
+    // of phase.  Measured at duration 500, episodes staggered (profiles/r02_tune_affinity_period.log):
+    // every 128 steps 42.4 us per step, 64: 41.3, 32: 40.6, 16: 40.5, 8: 41.6 (a re-sort is four
+    // small launches, ~25 us) -> re-sort after ~6 % of the envs have moved; 128 when episodes
+    // only end by the drawdown rule or at the end of the data.
+    int auto_period = 128;
+    if (p.max_dur > 0) {
+      auto_period = p.max_dur / 16;
+      auto_period = auto_period < 8 ? 8 : (auto_period > 128 ? 128 : auto_period);
+    }
+    const int period = cfg->affinity_period == 0 ? auto_period : cfg->affinity_period;
     const int EPB = epw * 4;
     const int n_wg = (p.N + EPB - 1) / EPB;
     if (period > 0 && n_wg >= 64 && vpe * E->vec * 4 >= 512) {
@@ -1060,6 +1090,100 @@ int gte_get_final_state(gte_env* E, gte_state_view* out) {
   return GTE_OK;
 }
 
+// ---------------------------------------------------------------------------
+// multi-GPU: the return all-gather over RCCL (gte_comm.hip)
+
+int gte_comm_unique_id(uint8_t* id_out) {
+  if (!id_out) return fail(GTE_ERR_INVALID, "id_out is NULL");
+  if (const char* why = gte::rccl_load()) return fail(GTE_ERR_STATE, "RCCL unavailable: %s", why);
+  const int r = gte::rccl_unique_id(id_out);
+  if (r != 0) return fail(GTE_ERR_HIP, "ncclGetUniqueId: %s", gte::rccl_error(r));
+  return GTE_OK;
+}
+
+int gte_comm_init(gte_env* E, const uint8_t* id, int32_t rank, int32_t world) {
+  if (!E || !id) return fail(GTE_ERR_INVALID, "NULL argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(GTE_ERR_INVALID, "rank %d of %d", rank, world);
+  if (E->comm) return fail(GTE_ERR_STATE, "the env already has a communicator");
+  if (const char* why = gte::rccl_load()) return fail(GTE_ERR_STATE, "RCCL unavailable: %s", why);
+  HIPCHK(hipSetDevice(E->cfg.device));
+  const int r = gte::rccl_comm_init(&E->comm, id, rank, world);
+  if (r != 0) { E->comm = nullptr; return fail(GTE_ERR_HIP, "ncclCommInitRank: %s", gte::rccl_error(r)); }
+  E->comm_rank = rank;
+  E->comm_world = world;
+  HIPCHK(hipStreamCreateWithFlags(&E->comm_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&E->comm_ready, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&E->comm_done, hipEventDisableTiming));
+  TRY(dev_alloc(E, &E->gathered_returns, (size_t)world * 6 * (size_t)E->p.N));
+  HIPCHK(hipDeviceSynchronize());
+  return GTE_OK;
+}
+
+int gte_allgather(gte_env* E, const void* src_device, void* dst_device, uint64_t bytes_per_rank,
+                  int32_t mode) {
+  if (!E || !src_device || !dst_device) return fail(GTE_ERR_INVALID, "NULL argument");
+  if (!E->comm) return fail(GTE_ERR_STATE, "gte_allgather before gte_comm_init");
+  if (mode != 0 && mode != 1) return fail(GTE_ERR_INVALID, "mode must be 0 (env stream) or 1 (overlapped)");
+  hipStream_t s = E->stream;
+  if (mode == 1) {  // behind everything enqueued so far, beside everything enqueued later
+    HIPCHK(hipEventRecord(E->comm_ready, E->stream));
+    HIPCHK(hipStreamWaitEvent(E->comm_stream, E->comm_ready, 0));
+    s = E->comm_stream;
+  }
+  const int r = gte::rccl_allgather_bytes(E->comm, src_device, dst_device, (size_t)bytes_per_rank, s);
+  if (r != 0) return fail(GTE_ERR_HIP, "ncclAllGather: %s", gte::rccl_error(r));
+  if (mode == 1) HIPCHK(hipEventRecord(E->comm_done, E->comm_stream));
+  return GTE_OK;
+}
+
+int gte_allgather_returns(gte_env* E, void* dst_device, int32_t mode, const void** gathered) {
+  if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
+  if (!E->comm) return fail(GTE_ERR_STATE, "gte_allgather_returns before gte_comm_init");
+  const Params& p = E->p;
+  const size_t N = (size_t)p.N;
+  if ((const uint8_t*)p.terminated != (const uint8_t*)p.reward + 4 * N || p.truncated != p.terminated + N)
+    return fail(GTE_ERR_STATE, "the bound return buffers are not one packed [reward f32 | terminated u8 "
+                               "| truncated u8] block of 6N bytes");
+  void* dst = dst_device ? dst_device : (void*)E->gathered_returns;
+  TRY(gte_allgather(E, p.reward, dst, 6 * N, mode));
+  if (gathered) *gathered = dst;
+  return GTE_OK;
+}
+
+int gte_allgather_obs(gte_env* E, float* dst_device, int32_t mode) {
+  if (!E || !dst_device) return fail(GTE_ERR_INVALID, "NULL argument");
+  const Params& p = E->p;
+  return gte_allgather(E, p.obs, dst_device, sizeof(float) * (size_t)p.N * p.W * p.Fobs, mode);
+}
+
+int gte_comm_wait(gte_env* E) {
+  if (!E || !E->comm) return fail(GTE_ERR_STATE, "no communicator");
+  HIPCHK(hipStreamWaitEvent(E->stream, E->comm_done, 0));
+  return GTE_OK;
+}
+
+int gte_comm_synchronize(gte_env* E) {
+  if (!E || !E->comm) return fail(GTE_ERR_STATE, "no communicator");
+  HIPCHK(hipStreamSynchronize(E->comm_stream));
+  return GTE_OK;
+}
+
+int gte_comm_destroy(gte_env* E) {
+  if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
+  if (!E->comm) return GTE_OK;
+  (void)hipStreamSynchronize(E->stream);
+  (void)hipStreamSynchronize(E->comm_stream);
+  const int r = gte::rccl_comm_destroy(E->comm);
+  E->comm = nullptr;
+  if (E->comm_ready) (void)hipEventDestroy(E->comm_ready);
+  if (E->comm_done) (void)hipEventDestroy(E->comm_done);
+  if (E->comm_stream) (void)hipStreamDestroy(E->comm_stream);
+  E->comm_ready = E->comm_done = nullptr;
+  E->comm_stream = nullptr;
+  if (r != 0) return fail(GTE_ERR_HIP, "ncclCommDestroy: %s", gte::rccl_error(r));
+  return GTE_OK;
+}
+
 int gte_set_stream(gte_env* E, void* hip_stream) {
   if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
   HIPCHK(hipStreamSynchronize(E->stream));
@@ -1136,6 +1260,7 @@ int gte_debug_set_stamps(gte_env* E, void* device_buf) {
 void gte_destroy(gte_env* E) {
   if (!E) return;
   (void)hipSetDevice(E->cfg.device);
+  (void)gte_comm_destroy(E);
   (void)hipStreamSynchronize(E->stream);
   if (E->own_stream) (void)hipStreamSynchronize(E->own_stream);
   for (void* ptr : E->allocs) (void)hipFree(ptr);

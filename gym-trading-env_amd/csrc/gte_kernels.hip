@@ -346,10 +346,12 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
       if (ended && p.autoreset == GTE_AUTORESET_SAME_STEP) {
         // the reference's step() runs _get_obs (:272) before any wrapper resets the env:
         // write the terminal row's dynamic features, remember the terminal window
+#ifndef GTE_HOT_ONLY  // (the isolated hot instantiations never run with final_obs)
         if (p.final_rec) {  // what the wrapper's `final_info` reports (state before the reset)
           store_state_at(&p.final_rec[e], s);
           p.final_rec[e].start = s.start;
         }
+#endif
         ObsJob term;
         make_job(p, e, s, false, term);
         int32_t qi, qp, qd;

@@ -134,6 +134,77 @@ class PendingReturns:
         return self._owner._views(self._buf)
 
 
+class NativeReturnGather:
+    """The per-step return all-gather through libgte's OWN RCCL communicator
+    (`gte_comm_init` / `gte_allgather_returns`, csrc/gte_comm.hip): the collective is enqueued by
+    the library on the env's stream right behind the step kernel — no torch.distributed call, no
+    host synchronisation, no cross-stream event per step.  torch.distributed is used ONCE, as
+    the host channel that hands rank 0's communicator id to the other ranks (any backend).
+
+    `gather()` -> (reward f32 [world, n], terminated bool [world, n], truncated bool [world, n])
+    views of the gathered buffer, stream-ordered on the env's stream (torch's current stream for
+    an env built with output="torch").  `lib` / `handle` let the id exchange and the view layout
+    be exercised without a GPU (tests/test_distributed_cpu.py)."""
+
+    def __init__(self, env, group=None, with_obs=False, lib=None, handle=None, mode=0):
+        import ctypes as C
+        from . import _abi
+        self._C, self._abi = C, _abi
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.lib = lib if lib is not None else env._lib
+        self.handle = handle if handle is not None else env._h
+        self.n = int(env.num_envs)
+        self.mode = int(mode)
+        self.lay = packed_layout(self.n)
+        ident = (C.c_uint8 * _abi.GTE_COMM_ID_BYTES)()
+        if self.rank == 0:
+            _abi.check(self.lib, self.lib.gte_comm_unique_id(ident))
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                                   group=group)
+        ident = (C.c_uint8 * _abi.GTE_COMM_ID_BYTES).from_buffer_copy(box[0])
+        _abi.check(self.lib, self.lib.gte_comm_init(self.handle, ident, self.rank, self.world))
+        dev = env.packed_returns.device
+        self.buf = torch.empty(self.world * self.lay["bytes"], dtype=torch.uint8, device=dev)
+        self.obs_buf = None
+        if with_obs:
+            self.obs_buf = torch.empty((self.world * self.n,) + tuple(env.obs_shape),
+                                       dtype=torch.float32, device=dev)
+        self._closed = False
+
+    def gather(self):
+        """All-gather the packed returns of the step just enqueued."""
+        out = self._C.c_void_p()
+        self._abi.check(self.lib, self.lib.gte_allgather_returns(
+            self.handle, self._C.c_void_p(self.buf.data_ptr()), self.mode, self._C.byref(out)))
+        return self.views()
+
+    def views(self):
+        rows = self.buf.view(self.world, self.lay["bytes"])
+        r0, r1 = self.lay["reward"]
+        t0, t1 = self.lay["terminated"]
+        u0, u1 = self.lay["truncated"]
+        return (rows[:, r0:r1].view(torch.float32), rows[:, t0:t1].view(torch.bool),
+                rows[:, u0:u1].view(torch.bool))
+
+    def gather_obs(self):
+        if self.obs_buf is None:
+            raise ValueError("constructed without with_obs=True")
+        self._abi.check(self.lib, self.lib.gte_allgather_obs(
+            self.handle, self._C.c_void_p(self.obs_buf.data_ptr()), self.mode))
+        return self.obs_buf
+
+    def wait(self):
+        """mode 1: order the env's stream after the last overlapped gather."""
+        self._abi.check(self.lib, self.lib.gte_comm_wait(self.handle))
+
+    def close(self):
+        if not self._closed:
+            self._closed = True
+            self._abi.check(self.lib, self.lib.gte_comm_destroy(self.handle))
+
+
 class ReturnPipeline:
     """Block-wise, overlapped all-gather of a BatchedTradingEnv's returns.
 
@@ -206,7 +277,7 @@ class ShardedTradingEnv:
     only ever visit those)."""
 
     def __init__(self, df, global_envs: int, *, group=None, device=None, gather_obs=False,
-                 pipeline=1, block=1, partition_datasets=False, **kw):
+                 pipeline=1, block=1, partition_datasets=False, native_gather=False, **kw):
         from .batched import BatchedTradingEnv
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
@@ -230,6 +301,10 @@ class ShardedTradingEnv:
         obs_shape = self.env.obs_shape if gather_obs else None
         # step(): synchronous per-step gather; step_async(): the pipeline (own buffers)
         self.returns = ReturnGather(self.n_local, dev, group, obs_shape=obs_shape)
+        # native_gather=True: step() gathers through libgte's own RCCL communicator, enqueued
+        # by the library behind the step kernel (GPU backends only)
+        self.native = (NativeReturnGather(self.env, group, with_obs=gather_obs)
+                       if native_gather else None)
         self._pipe = None
         if self.pipeline >= 2:
             self._pipe = ReturnPipeline(self.env, ReturnGather(self.n_local, dev, group,
@@ -244,6 +319,11 @@ class ShardedTradingEnv:
         if self._pipe is not None:
             self._pipe.before_step()  # never rewrite rows a pending block gather still reads
         obs, _, _, _, info = self.env.step(local_actions)
+        if self.native is not None:
+            reward, term, trunc = self.native.gather()
+            if self.gather_obs:
+                obs = self.native.gather_obs()
+            return obs, reward, term, trunc, info
         reward, term, trunc = self.returns.gather(self.env.packed_returns)
         if self.gather_obs:
             obs = self.returns.gather_obs(obs)
@@ -271,4 +351,6 @@ class ShardedTradingEnv:
 
     def close(self):
         self.drain()
+        if self.native is not None:
+            self.native.close()
         self.env.close()

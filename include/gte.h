@@ -132,7 +132,8 @@ typedef struct gte_config {
   int32_t affinity_period;  /* L2-affinity processing order: every this many steps the
                                envs are re-sorted by (dataset, table region) so that
                                each XCD's L2 serves one region (speed only; results
-                               do not depend on it).  0 = default (128), -1 = off   */
+                               do not depend on it).  0 = default (max_episode_duration
+                               / 16 within [8, 128]; 128 for 'max'), -1 = off        */
   int32_t log_steps;        /* L > 0: keep the last L steps of every env in a device
                                trajectory log (what History records each step,
                                environments.py:253-264); 0 = off                  */
@@ -350,6 +351,37 @@ int gte_bind_outputs(gte_env* env, const gte_outputs* bufs);
  * All three pointers are required; the caller keeps the buffers alive while steps that
  * write them or collectives that read them are in flight. */
 int gte_bind_returns(gte_env* env, float* reward, uint8_t* terminated, uint8_t* truncated);
+
+/* ---- multi-GPU: the ONE exchange of the sharded path.  Environments shard over
+ * the GPUs of a node with no data-path collective; what a caller of the reference's vector env
+ * gets back from step() — `reward, done, truncated` for ALL environments (environments.py:272,
+ * docs/source/vectorize_env.rst:55-65) — is assembled by an RCCL all-gather over xGMI of the
+ * packed per-shard records (reward f32 [N] | terminated u8 [N] | truncated u8 [N], the layout the
+ * step kernel writes), and on request of the observations.  One process per GPU; RCCL is bound
+ * at run time (no link-time dependency). */
+#define GTE_COMM_ID_BYTES 128
+/* rank 0 creates the id (ncclGetUniqueId) and hands it to every rank by any host channel */
+int gte_comm_unique_id(uint8_t* id_out /* [GTE_COMM_ID_BYTES] */);
+/* every rank, collectively: one communicator per env (equal n_envs on every rank) */
+int gte_comm_init(gte_env* env, const uint8_t* id, int32_t rank, int32_t world);
+/* all-gather `bytes_per_rank` bytes from src_device into dst_device [world * bytes_per_rank]
+ * (rank r's block at offset r * bytes_per_rank).  mode 0: on the env's stream — stream-ordered
+ * between two steps, no host synchronisation (the synchronous per-step form); mode 1: on the
+ * library's communication stream behind an event on the env's stream, overlapping the launches
+ * enqueued afterwards (the caller keeps src intact meanwhile: gte_bind_returns rotates return
+ * buffers; a block of K rotated rows is one contiguous src) — join with gte_comm_wait (orders
+ * the env's stream after the last mode-1 gather) or gte_comm_synchronize (blocks the host). */
+int gte_allgather(gte_env* env, const void* src_device, void* dst_device,
+                  uint64_t bytes_per_rank, int32_t mode);
+/* the packed returns of the last step: 6N bytes per rank -> u8 [world, 6N] in dst_device, or in
+ * a library-owned buffer when dst_device is NULL (*gathered receives the address used) */
+int gte_allgather_returns(gte_env* env, void* dst_device, int32_t mode, const void** gathered);
+/* the observations of the last step -> f32 [world * N, W, F_obs] (xGMI-bound at the headline
+ * shape: 168 MB per rank and step) */
+int gte_allgather_obs(gte_env* env, float* dst_device, int32_t mode);
+int gte_comm_wait(gte_env* env);
+int gte_comm_synchronize(gte_env* env);
+int gte_comm_destroy(gte_env* env); /* also done by gte_destroy */
 
 /* Run on exactly this hipStream_t; NULL is HIP's null (default) stream, which is
  * what PyTorch's default stream is.  A new env runs on a private non-blocking

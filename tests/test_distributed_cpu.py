@@ -139,6 +139,111 @@ def _block_worker(rank, world, port, out_dir, block, depth, steps):
     dist.destroy_process_group()
 
 
+class _HostCommLib:
+    """Stand-in for libgte's communicator entry points (include/gte.h, gte_comm_*) over HOST
+    memory and gloo, so that NativeReturnGather's id exchange, call sequence and view layout run
+    without a GPU.  `handle` is this object's env stub; pointers are host addresses."""
+
+    def __init__(self, env):
+        self.env, self.rank, self.world, self.id_seen = env, None, None, None
+
+    def gte_last_error(self):
+        return b"stub"
+
+    def gte_comm_unique_id(self, ident):
+        for i in range(128):
+            ident[i] = (i * 7 + 3) % 251  # what rank 0 "generated"
+        return 0
+
+    def gte_comm_init(self, handle, ident, rank, world):
+        self.id_seen, self.rank, self.world = bytes(ident), rank, world
+        return 0
+
+    def _into(self, ptr, nbytes, src):
+        import ctypes
+        parts = [torch.empty_like(src) for _ in range(self.world)]
+        dist.all_gather(parts, src)
+        flat = torch.cat([x.view(torch.uint8).reshape(-1) for x in parts])
+        dst = np.frombuffer((ctypes.c_char * nbytes).from_address(ptr.value), dtype=np.uint8)
+        dst[:] = flat.numpy()
+
+    def gte_allgather_returns(self, handle, dst, mode, out):
+        self._into(dst, self.world * 6 * self.env.num_envs, self.env.packed_returns)
+        return 0
+
+    def gte_allgather_obs(self, handle, dst, mode):
+        self._into(dst, self.world * self.env.obs.numel() * 4, self.env.obs)
+        return 0
+
+    def gte_comm_destroy(self, handle):
+        return 0
+
+
+def _native_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gym_trading_env_amd.config import make_config
+    from gym_trading_env_amd.distributed import NativeReturnGather, ReturnGather, pack_returns, shard_range
+    from oracle import oracle
+    first, n = shard_range(G, world, rank)
+    ora = oracle.OracleEnv(make_config(n_envs=n, n_static=3, env_id_base=first, **KW), [_data()])
+    ora.reset()
+
+    class Env:  # what NativeReturnGather reads from a BatchedTradingEnv
+        num_envs, obs_shape = n, (4, 5)
+        packed_returns = torch.zeros(6 * n, dtype=torch.uint8)
+        obs = torch.zeros((n, 4, 5), dtype=torch.float32)
+    env = Env()
+    lib = _HostCommLib(env)
+    native = NativeReturnGather(env, with_obs=True, lib=lib, handle=0)
+    assert lib.rank == rank and lib.world == world
+    assert lib.id_seen == bytes((i * 7 + 3) % 251 for i in range(128))  # rank 0's id reached every rank
+    ref = ReturnGather(n, "cpu", obs_shape=(4, 5))
+    actions = np.random.default_rng(5).integers(-1, 3, (STEPS, G)).astype(np.int32)
+    rec = []
+    for k in range(STEPS):
+        ora.step(actions[k, first:first + n])
+        pack_returns(torch.from_numpy(ora.reward.copy()), torch.from_numpy(ora.terminated.copy()).bool(),
+                     torch.from_numpy(ora.truncated.copy()).bool(), out=env.packed_returns)
+        env.obs.copy_(torch.from_numpy(ora.obs))
+        reward, term, trunc = native.gather()
+        r2, t2, u2 = ref.gather(env.packed_returns)  # the torch.distributed wrapper: same views
+        assert torch.equal(reward, r2) and torch.equal(term, t2) and torch.equal(trunc, u2)
+        obs = native.gather_obs()
+        assert torch.equal(obs, ref.gather_obs(env.obs))
+        rec.append((reward.reshape(-1).numpy().copy(), term.reshape(-1).numpy().copy(),
+                    trunc.reshape(-1).numpy().copy(), obs.numpy().copy()))
+    native.close()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "native.npz"), reward=np.stack([r[0] for r in rec]),
+                 term=np.stack([r[1] for r in rec]), trunc=np.stack([r[2] for r in rec]),
+                 obs=np.stack([r[3] for r in rec]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_native_return_gather_wrapper_two_ranks(tmp_path, oracle_mod):
+    """NativeReturnGather (the Python face of gte_comm_init / gte_allgather_returns /
+    gte_allgather_obs): rank 0's communicator id reaches every rank, the gathered views have
+    the layout of the torch.distributed wrapper, and the sharded run equals the unsharded one.
+    The library calls are served by a host/gloo stand-in here; the real RCCL path runs in
+    tests/test_gpu_distributed.py."""
+    from gym_trading_env_amd.config import make_config
+    port = 29700 + os.getpid() % 200
+    mp.spawn(_native_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "native.npz")
+    env = oracle_mod.OracleEnv(make_config(n_envs=G, n_static=3, env_id_base=0, **KW), [_data()])
+    env.reset()
+    actions = np.random.default_rng(5).integers(-1, 3, (STEPS, G)).astype(np.int32)
+    for k in range(STEPS):
+        env.step(actions[k])
+        np.testing.assert_array_equal(got["reward"][k], env.reward)
+        np.testing.assert_array_equal(got["term"][k], env.terminated.astype(bool))
+        np.testing.assert_array_equal(got["trunc"][k], env.truncated.astype(bool))
+        np.testing.assert_array_equal(got["obs"][k], env.obs)
+
+
 @pytest.mark.parametrize("block,depth,steps", [(4, 2, 30), (1, 3, 20), (8, 2, 16)])
 def test_block_pipeline_two_ranks_equals_unsharded(tmp_path, oracle_mod, block, depth, steps):
     """ReturnPipeline: returns gathered a block at a time, `depth` blocks in rotation, handles

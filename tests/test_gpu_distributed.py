@@ -85,6 +85,94 @@ def test_sharded_env_single_rank_nccl(oracle_mod):
         dist.destroy_process_group()
 
 
+def test_c_abi_allgather_single_rank_rccl(oracle_mod):
+    """gte_comm_unique_id / gte_comm_init / gte_allgather_returns / gte_allgather_obs /
+    gte_allgather (include/gte.h): the return exchange through libgte's own RCCL communicator,
+    driven through the C ABI alone (ctypes, no torch on the path), 1-rank group on the test box:
+    the collective degenerates to a copy but runs RCCL's real code path.  Mode 0 (env stream)
+    and mode 1 (communication stream + gte_comm_wait) against the oracle."""
+    import ctypes as C
+    from gym_trading_env_amd import _abi
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    rng = np.random.default_rng(1)
+    T, Fs, N = 300, 6, 900
+    close = 100 * np.exp(np.cumsum(rng.normal(0, 1e-2, T)))
+    feat = rng.normal(0, 1, (T, Fs)).astype(np.float32)
+    env = BatchedTradingEnv((feat, close), num_envs=N, positions=[-1, 0, 1], windows=5, trading_fees=1e-4,
+                            max_episode_duration=20, autoreset="next_step", seed=4, output="numpy")
+    lib, h = env._lib, env._h
+    full = np.zeros((T, Fs + 2), np.float32); full[:, :Fs] = feat
+    ora = oracle_mod.OracleEnv(env.cfg, [(full, close)])
+    ident = (C.c_uint8 * _abi.GTE_COMM_ID_BYTES)()
+    with pytest.raises(_abi.GteError, match="gte_comm_init"):
+        _abi.check(lib, lib.gte_allgather_returns(h, None, 0, None))
+    _abi.check(lib, lib.gte_comm_unique_id(ident))
+    assert any(ident)
+    _abi.check(lib, lib.gte_comm_init(h, ident, 0, 1))
+    with pytest.raises(_abi.GteError, match="already"):
+        _abi.check(lib, lib.gte_comm_init(h, ident, 0, 1))
+    env.reset(); ora.reset()
+    out = C.c_void_p()
+    for k in range(45):
+        a = rng.integers(-1, 3, N).astype(np.int32)
+        env._launch_step(a); ora.step(a)
+        mode = k % 2
+        _abi.check(lib, lib.gte_allgather_returns(h, None, mode, C.byref(out)))
+        if mode == 1:
+            _abi.check(lib, lib.gte_comm_wait(h))  # the env's stream now follows the gather
+        packed = env._to_host(out.value, np.uint8, 6 * N)
+        np.testing.assert_array_equal(packed[:4 * N].view(np.float32), ora.reward)
+        np.testing.assert_array_equal(packed[4 * N:5 * N], ora.terminated)
+        np.testing.assert_array_equal(packed[5 * N:], ora.truncated)
+    # observations, and the generic form on an arbitrary device buffer (here: reward64)
+    env2 = BatchedTradingEnv((feat, close), num_envs=N, positions=[-1, 0, 1], windows=5, output="numpy")
+    env2.reset()  # a second env only lends device memory to receive into
+    _abi.check(lib, lib.gte_allgather_obs(h, C.c_void_p(env2._out.obs), 0))
+    np.testing.assert_array_equal(env2._to_host(env2._out.obs, np.float32, N * 5 * 8).reshape(N, 5, 8), ora.obs)
+    _abi.check(lib, lib.gte_allgather(h, C.c_void_p(env._out.reward64), C.c_void_p(env2._out.reward64), 8 * N, 1))
+    _abi.check(lib, lib.gte_comm_synchronize(h))
+    np.testing.assert_array_equal(env2._to_host(env2._out.reward64, np.float64, N), ora.reward64)
+    _abi.check(lib, lib.gte_comm_destroy(h))
+    _abi.check(lib, lib.gte_comm_destroy(h))  # idempotent
+    env2.close()
+    env.close()
+
+
+def test_sharded_env_native_gather_single_rank(oracle_mod):
+    """ShardedTradingEnv(native_gather=True): step() gathers through libgte's communicator
+    (NativeReturnGather) instead of torch.distributed; same results."""
+    import torch
+    import torch.distributed as dist
+    from gym_trading_env_amd.distributed import ShardedTradingEnv
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 1000))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=0, world_size=1)  # only the id hand-off uses it
+    try:
+        rng = np.random.default_rng(0)
+        T, Fs, G = 300, 6, 640
+        close = 100 * np.exp(np.cumsum(rng.normal(0, 1e-2, T)))
+        feat = rng.normal(0, 1, (T, Fs)).astype(np.float32)
+        env = ShardedTradingEnv((feat, close), G, gather_obs=True, native_gather=True, device=0,
+                                positions=[-1, 0, 1], windows=5, trading_fees=1e-4,
+                                max_episode_duration=20, autoreset="next_step", seed=4)
+        full = np.zeros((T, Fs + 2), np.float32); full[:, :Fs] = feat
+        ora = oracle_mod.OracleEnv(env.env.cfg, [(full, close)])
+        env.reset(); ora.reset()
+        for k in range(30):
+            a = rng.integers(-1, 3, G).astype(np.int32)
+            obs, reward, term, trunc, _ = env.step(torch.from_numpy(a).cuda())
+            ora.step(a)
+            assert reward.shape == (1, G) and obs.shape == (G, 5, 8)
+            np.testing.assert_array_equal(obs.cpu().numpy(), ora.obs)
+            np.testing.assert_array_equal(reward.cpu().numpy().reshape(-1), ora.reward)
+            np.testing.assert_array_equal(term.cpu().numpy().reshape(-1), ora.terminated.astype(bool))
+            np.testing.assert_array_equal(trunc.cpu().numpy().reshape(-1), ora.truncated.astype(bool))
+        env.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_return_slots_keep_older_returns_intact(oracle_mod):
     """return_slots=3: step t writes packed buffer t % 3; the buffers of steps t-1 and t-2
     still hold those steps' returns (what an all-gather in flight reads)."""
