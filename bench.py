@@ -299,11 +299,17 @@ def main():
                     help="skip the 262 144-env leg (observations streamed to HBM)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--gather-obs", action="store_true", help="also all-gather observations (N>1)")
-    ap.add_argument("--gather-mode", default="block", choices=["block", "step", "torch-step"],
-                    help="N>1: 'block' = asynchronous all-gather of --gather-every step blocks "
-                         "(torch.distributed); 'step' = synchronous per-step all-gather through "
-                         "libgte's own RCCL communicator (gte_allgather_returns); 'torch-step' = "
-                         "synchronous per-step through torch.distributed")
+    ap.add_argument("--gather-mode", default="step", choices=["step", "step-overlap", "block", "torch-step"],
+                    help="N>1, the mode `value` is measured in: 'step' = synchronous per-step "
+                         "all-gather through libgte's own RCCL communicator (gte_allgather_returns, "
+                         "what the north star describes); 'step-overlap' = the same on the library's "
+                         "communication stream, overlapping the next step (returns one step late); "
+                         "'block' = asynchronous all-gather of --gather-every step blocks "
+                         "(torch.distributed); 'torch-step' = synchronous per-step through "
+                         "torch.distributed.  The other modes are measured too and reported under "
+                         "config.other_gather_modes")
+    ap.add_argument("--one-gather-mode", action="store_true",
+                    help="N>1: measure only --gather-mode")
     ap.add_argument("--gather-every", type=int, default=32,
                     help="block mode: all-gather the returns in blocks of this many steps (every "
                          "step's reward/flags still cross xGMI inside the timed region)")
@@ -366,9 +372,14 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    mode = args.gather_mode if use_dist else None
-    depth = max(2, args.gather_depth) if mode == "block" else 1
-    block = max(1, args.gather_every) if mode == "block" else 1
+    modes = []
+    if use_dist:
+        modes = [args.gather_mode] + ([] if args.one_gather_mode else
+                                      [m for m in ("step", "step-overlap", "block") if m != args.gather_mode])
+        if backend != "nccl":  # the library's communicator is RCCL: gloo rehearsals use torch's
+            modes = [m for m in modes if m in ("block", "torch-step")] or ["block"]
+    depth = max(2, args.gather_depth)
+    block = max(1, args.gather_every)
 
     env = make_env(args, wl, N, rank, local_rank, return_slots=depth * block if use_dist else 1)
     gen = torch.Generator(device=dev)
@@ -388,65 +399,78 @@ def main():
     # the return of a sharded run: RCCL all-gather of the packed (reward f32 | terminated u8 |
     # truncated u8) records, 6 bytes per env and step, which the kernel writes directly in
     # that layout
-    returns = pipe = comm = None
+    comm = returns = pipe = None
     if use_dist:
         from gym_trading_env_amd.distributed import ReturnGather, ReturnPipeline
-        if mode == "step" and backend == "nccl":
+        if any(m in ("step", "step-overlap") for m in modes):
             from gym_trading_env_amd.distributed import NativeReturnGather
-            comm = NativeReturnGather(env, with_obs=args.gather_obs)  # libgte's own communicator
-        else:
-            returns = ReturnGather(N, dev, obs_shape=env.obs_shape if args.gather_obs else None,
-                                   depth=depth, block=block)
+            comm = NativeReturnGather(env, with_obs=args.gather_obs, mode=1)  # libgte's own communicator
+        returns = ReturnGather(N, dev, obs_shape=env.obs_shape if args.gather_obs else None,
+                               depth=depth, block=block)
+        returns1 = ReturnGather(N, dev)  # torch-step: plain synchronous gather
+        pipe = ReturnPipeline(env, returns, block, depth)
+
+    def timed(mode, first_step):
+        """W warm-up + K timed steps with the returns gathered the `mode` way -> (wall s, event ms)."""
+        def one_step(i):
             if mode == "block":
-                pipe = ReturnPipeline(env, returns, block, depth)
+                pipe.before_step()  # rows about to be rewritten must have been gathered
+            elif mode == "step-overlap":
+                comm.wait(1)        # the gather of step t-2 has released what step t rewrites
+            obs = env.step(actions[i % n_rows])[0]
+            if mode == "block":
+                pipe.after_step()   # starts the block's all-gather on block boundaries
+            elif mode == "step":
+                comm.mode = 0       # ncclAllGather on the env's stream, right behind the step kernel
+                comm.gather()
+            elif mode == "step-overlap":
+                comm.mode = 1       # on the communication stream, beside the next step
+                comm.gather()
+            elif mode == "torch-step":
+                returns1.gather(env.packed_returns)
+            if mode is not None and args.gather_obs:
+                (comm.gather_obs() if mode in ("step", "step-overlap") else returns.gather_obs(obs))
 
-    def drain():
-        if pipe is not None:
-            pipe.flush()  # incl. a block the step count left unfinished
+        def drain():
+            if mode == "block":
+                pipe.flush()  # incl. a block the step count left unfinished
+            elif mode == "step-overlap":
+                comm.wait(0)
 
-    def one_step(i):
-        if pipe is not None:
-            pipe.before_step()  # rows about to be rewritten must have been gathered
-        env.step(actions[i % n_rows])
-        if pipe is not None:
-            pipe.after_step()   # starts the block's all-gather on block boundaries
-        elif comm is not None:
-            comm.gather()       # ncclAllGather on the env's stream, stream-ordered after the step
-            if args.gather_obs:
-                comm.gather_obs()
-        elif returns is not None:
-            returns.gather(env.packed_returns)
-            if args.gather_obs:
-                returns.gather_obs(env._t["obs"])
-        if pipe is not None and args.gather_obs:
-            returns.gather_obs(env._t["obs"])
+        for i in range(args.warmup):
+            one_step(first_step + i)
+        drain()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        env.timer_start()  # HIP events on the stream the kernel is launched on
+        for i in range(args.steps):
+            one_step(first_step + args.warmup + i)
+        drain()  # every all-gather belongs to the timed region
+        ev_ms = env.timer_stop()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el, ev_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el, ev_ms = float(t[0]), float(t[1])
+        return el, ev_ms
 
-    for i in range(args.warmup):
-        one_step(i)
-    drain()
     episodes0 = int(env.state("episode").sum())
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    env.timer_start()  # HIP events on the stream the kernel is launched on
-    for i in range(args.steps):
-        one_step(args.warmup + i)
-    drain()  # every all-gather belongs to the timed region
-    ev_ms = env.timer_stop()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el, ev_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el, ev_ms = float(t[0]), float(t[1])
-
-    # episodes really end inside the timed region (auto-reset is part of the step)
+    el, ev_ms = timed(modes[0] if modes else None, 0)
     episodes = int(env.state("episode").sum()) - episodes0
+    mode = modes[0] if modes else None
+    other_modes = {}
+    for k, m in enumerate(modes[1:]):
+        e2, _ = timed(m, (k + 1) * (args.warmup + args.steps))
+        other_modes[m] = {"ms_per_step": e2 * 1e3 / args.steps, "value": world * N * args.steps / e2}
+
+    # (episodes really end inside the timed region: auto-reset is part of the step)
     info = env.launch_info()
     kernel_us = ev_ms * 1e3 / args.steps
     if comm is not None:
@@ -474,11 +498,15 @@ def main():
 
     if rank == 0:
         par = f"env-shard x{world}"
+        how = {"block": f" in {block}-step blocks overlapping the following steps (torch.distributed): "
+                        f"global returns arrive up to {block} steps late",
+               "step": ", synchronous after every step on the env's stream, libgte's own RCCL "
+                       "communicator (C ABI gte_allgather_returns): per-step global returns",
+               "step-overlap": ", after every step on libgte's communication stream, overlapping the "
+                               "next step (gte_allgather_returns mode 1): global returns one step late",
+               "torch-step": ", synchronous per step (torch.distributed)"}
         if use_dist:
-            par += " + RCCL all-gather(reward,flags" + (",obs)" if args.gather_obs else ")")
-            par += {"block": f" in {block}-step blocks overlapping the following steps (torch.distributed)",
-                    "step": ", synchronous per step, libgte's own RCCL communicator (C ABI)",
-                    "torch-step": ", synchronous per step (torch.distributed)"}[mode]
+            par += " + RCCL all-gather(reward,flags" + (",obs)" if args.gather_obs else ")") + how[mode]
         out = {
             "metric": "env-steps/sec", "value": world * N * args.steps / el, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -496,6 +524,10 @@ def main():
             "roofline": roofline_block(N, kernel_us, shape,
                                        live.get(N) or recorded_traffic(args.workload, N)),
         }
+        if other_modes:  # the same run with the returns gathered the other ways
+            out["config"]["other_gather_modes"] = {
+                m: dict(v, parallelism=f"env-shard x{world} + RCCL all-gather(reward,flags"
+                        + (",obs)" if args.gather_obs else ")") + how[m]) for m, v in other_modes.items()}
         if hbm:
             out["roofline"]["hbm_regime"] = hbm
         if world == 1 and not args.no_cpu_baseline:

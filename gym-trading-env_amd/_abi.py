@@ -202,7 +202,7 @@ SYMBOLS = {
     "gte_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]),
     "gte_allgather_returns": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, _P(C.c_void_p)]),
     "gte_allgather_obs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
-    "gte_comm_wait": (C.c_int, [C.c_void_p]),
+    "gte_comm_wait": (C.c_int, [C.c_void_p, C.c_int32]),
     "gte_comm_synchronize": (C.c_int, [C.c_void_p]),
     "gte_comm_destroy": (C.c_int, [C.c_void_p]),
     "gte_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -141,7 +141,9 @@ struct gte_env {
   void* comm = nullptr;
   int comm_rank = 0, comm_world = 0;
   hipStream_t comm_stream = nullptr;
-  hipEvent_t comm_ready = nullptr, comm_done = nullptr;
+  hipEvent_t comm_ready = nullptr;
+  hipEvent_t comm_done[4] = {nullptr, nullptr, nullptr, nullptr};  // ring: one per overlapped gather
+  int64_t comm_seq = 0;                                              // overlapped gathers so far
   uint8_t* gathered_returns = nullptr;  // u8 [world, 6N], library-owned destination
   void* h_snap = nullptr;  // pinned host memory for gte_read_envs: snapshots, then observations
   size_t h_snap_bytes = 0;
@@ -529,6 +531,16 @@ static int finalize(gte_env* E) {
     if (E->h_ds[d].T > maxT) maxT = E->h_ds[d].T;
   }
   p.depth = p.persist ? maxT : p.W;
+  // The L2-affinity order pays when each XCD's 4 MiB L2 can hold its 1/8 share of the feature
+  // tables (config 3: 12.8 MB).  Tables far beyond the 32 MiB of aggregate L2 (config 5: 1.6 GB
+  // per GPU, L2 hit rate 0.16 either way) only pay for the re-sorts and for scattered
+  // observation stores: 39.4 us per step with the order, 36.8 without
+  // (profiles/r02_c5_sweep.log).  Automatic (affinity_period = 0) turns it off there.
+  if (E->affinity_period > 0 && E->cfg.affinity_period == 0) {
+    size_t table_bytes = 0;
+    for (int d = 0; d < p.D; ++d) table_bytes += (size_t)E->h_ds[d].T * p.Fobs * sizeof(float);
+    if (table_bytes > ((size_t)64 << 20)) E->affinity_period = 0;
+  }
   TRY(dev_alloc(E, &p.ring, (size_t)p.N * p.depth * (p.nd ? p.nd : 1)));
   HIPCHK(hipDeviceSynchronize());
   E->finalized = true;
@@ -1113,7 +1125,7 @@ int gte_comm_init(gte_env* E, const uint8_t* id, int32_t rank, int32_t world) {
   E->comm_world = world;
   HIPCHK(hipStreamCreateWithFlags(&E->comm_stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&E->comm_ready, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&E->comm_done, hipEventDisableTiming));
+  for (auto& ev : E->comm_done) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   TRY(dev_alloc(E, &E->gathered_returns, (size_t)world * 6 * (size_t)E->p.N));
   HIPCHK(hipDeviceSynchronize());
   return GTE_OK;
@@ -1132,7 +1144,10 @@ int gte_allgather(gte_env* E, const void* src_device, void* dst_device, uint64_t
   }
   const int r = gte::rccl_allgather_bytes(E->comm, src_device, dst_device, (size_t)bytes_per_rank, s);
   if (r != 0) return fail(GTE_ERR_HIP, "ncclAllGather: %s", gte::rccl_error(r));
-  if (mode == 1) HIPCHK(hipEventRecord(E->comm_done, E->comm_stream));
+  if (mode == 1) {
+    HIPCHK(hipEventRecord(E->comm_done[E->comm_seq & 3], E->comm_stream));
+    E->comm_seq += 1;
+  }
   return GTE_OK;
 }
 
@@ -1156,9 +1171,12 @@ int gte_allgather_obs(gte_env* E, float* dst_device, int32_t mode) {
   return gte_allgather(E, p.obs, dst_device, sizeof(float) * (size_t)p.N * p.W * p.Fobs, mode);
 }
 
-int gte_comm_wait(gte_env* E) {
+int gte_comm_wait(gte_env* E, int32_t back) {
   if (!E || !E->comm) return fail(GTE_ERR_STATE, "no communicator");
-  HIPCHK(hipStreamWaitEvent(E->stream, E->comm_done, 0));
+  if (back < 0 || back > 3) return fail(GTE_ERR_INVALID, "back must be 0..3");
+  const int64_t k = E->comm_seq - 1 - back;  // the overlapped gather to wait for
+  if (k < 0) return GTE_OK;                  // not issued yet: nothing to wait for
+  HIPCHK(hipStreamWaitEvent(E->stream, E->comm_done[k & 3], 0));
   return GTE_OK;
 }
 
@@ -1176,9 +1194,10 @@ int gte_comm_destroy(gte_env* E) {
   const int r = gte::rccl_comm_destroy(E->comm);
   E->comm = nullptr;
   if (E->comm_ready) (void)hipEventDestroy(E->comm_ready);
-  if (E->comm_done) (void)hipEventDestroy(E->comm_done);
+  for (auto& ev : E->comm_done) { if (ev) (void)hipEventDestroy(ev); ev = nullptr; }
   if (E->comm_stream) (void)hipStreamDestroy(E->comm_stream);
-  E->comm_ready = E->comm_done = nullptr;
+  E->comm_ready = nullptr;
+  E->comm_seq = 0;
   E->comm_stream = nullptr;
   if (r != 0) return fail(GTE_ERR_HIP, "ncclCommDestroy: %s", gte::rccl_error(r));
   return GTE_OK;

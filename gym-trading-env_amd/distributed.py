@@ -166,7 +166,11 @@ class NativeReturnGather:
         ident = (C.c_uint8 * _abi.GTE_COMM_ID_BYTES).from_buffer_copy(box[0])
         _abi.check(self.lib, self.lib.gte_comm_init(self.handle, ident, self.rank, self.world))
         dev = env.packed_returns.device
-        self.buf = torch.empty(self.world * self.lay["bytes"], dtype=torch.uint8, device=dev)
+        # mode 1 keeps two gathers in flight: one destination per rotating return buffer
+        self.bufs = [torch.empty(self.world * self.lay["bytes"], dtype=torch.uint8, device=dev)
+                     for _ in range(2 if self.mode == 1 else 1)]
+        self.buf = self.bufs[0]
+        self._turn = 0
         self.obs_buf = None
         if with_obs:
             self.obs_buf = torch.empty((self.world * self.n,) + tuple(env.obs_shape),
@@ -176,12 +180,14 @@ class NativeReturnGather:
     def gather(self):
         """All-gather the packed returns of the step just enqueued."""
         out = self._C.c_void_p()
+        self.buf = self.bufs[self._turn % len(self.bufs)]
+        self._turn += 1
         self._abi.check(self.lib, self.lib.gte_allgather_returns(
             self.handle, self._C.c_void_p(self.buf.data_ptr()), self.mode, self._C.byref(out)))
         return self.views()
 
-    def views(self):
-        rows = self.buf.view(self.world, self.lay["bytes"])
+    def views(self, buf=None):
+        rows = (self.buf if buf is None else buf).view(self.world, self.lay["bytes"])
         r0, r1 = self.lay["reward"]
         t0, t1 = self.lay["terminated"]
         u0, u1 = self.lay["truncated"]
@@ -195,9 +201,12 @@ class NativeReturnGather:
             self.handle, self._C.c_void_p(self.obs_buf.data_ptr()), self.mode))
         return self.obs_buf
 
-    def wait(self):
-        """mode 1: order the env's stream after the last overlapped gather."""
-        self._abi.check(self.lib, self.lib.gte_comm_wait(self.handle))
+    def wait(self, back: int = 0):
+        """mode 1: order the env's stream after the overlapped gather issued `back` gathers ago
+        (0 = the last one).  With an env built with return_slots=2, `wait(1)` before every step
+        keeps one gather overlapping the next step while never letting a step rewrite a buffer a
+        gather still reads; views returned by gather() then describe the step after `wait(0)`."""
+        self._abi.check(self.lib, self.lib.gte_comm_wait(self.handle, int(back)))
 
     def close(self):
         if not self._closed:

@@ -369,8 +369,11 @@ int gte_comm_init(gte_env* env, const uint8_t* id, int32_t rank, int32_t world);
  * between two steps, no host synchronisation (the synchronous per-step form); mode 1: on the
  * library's communication stream behind an event on the env's stream, overlapping the launches
  * enqueued afterwards (the caller keeps src intact meanwhile: gte_bind_returns rotates return
- * buffers; a block of K rotated rows is one contiguous src) — join with gte_comm_wait (orders
- * the env's stream after the last mode-1 gather) or gte_comm_synchronize (blocks the host). */
+ * buffers; a block of K rotated rows is one contiguous src) — join with gte_comm_wait(env, back)
+ * (orders the env's stream after the mode-1 gather issued `back` gathers ago, 0 = the last one,
+ * up to 3: with two rotating return buffers, `gte_comm_wait(env, 1)` before step t makes the
+ * gather of step t-2 release the buffer step t rewrites while the gather of step t-1 still
+ * overlaps it) or gte_comm_synchronize (blocks the host). */
 int gte_allgather(gte_env* env, const void* src_device, void* dst_device,
                   uint64_t bytes_per_rank, int32_t mode);
 /* the packed returns of the last step: 6N bytes per rank -> u8 [world, 6N] in dst_device, or in
@@ -379,7 +382,7 @@ int gte_allgather_returns(gte_env* env, void* dst_device, int32_t mode, const vo
 /* the observations of the last step -> f32 [world * N, W, F_obs] (xGMI-bound at the headline
  * shape: 168 MB per rank and step) */
 int gte_allgather_obs(gte_env* env, float* dst_device, int32_t mode);
-int gte_comm_wait(gte_env* env);
+int gte_comm_wait(gte_env* env, int32_t back);
 int gte_comm_synchronize(gte_env* env);
 int gte_comm_destroy(gte_env* env); /* also done by gte_destroy */
 

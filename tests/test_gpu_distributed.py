@@ -119,7 +119,7 @@ def test_c_abi_allgather_single_rank_rccl(oracle_mod):
         mode = k % 2
         _abi.check(lib, lib.gte_allgather_returns(h, None, mode, C.byref(out)))
         if mode == 1:
-            _abi.check(lib, lib.gte_comm_wait(h))  # the env's stream now follows the gather
+            _abi.check(lib, lib.gte_comm_wait(h, 0))  # the env's stream now follows the gather
         packed = env._to_host(out.value, np.uint8, 6 * N)
         np.testing.assert_array_equal(packed[:4 * N].view(np.float32), ora.reward)
         np.testing.assert_array_equal(packed[4 * N:5 * N], ora.terminated)

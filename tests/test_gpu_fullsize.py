@@ -138,3 +138,63 @@ def test_automatic_geometry_and_store_policy(oracle_mod, n_envs, stores):
     assert info["resident_workgroups_per_cu"] >= 4 and 0.85 * slots <= info["n_blocks"] <= slots, info
     _compare_with_oracle(oracle_mod, [ds], n_envs=n_envs, steps=12, seed=5, check_every=6,
                          max_episode_duration=9, **C3)
+
+
+def test_config5_full_T_invariants():
+    """BASELINE config 5 at its real per-GPU size — 128 resident datasets x T = 100 000 rows
+    (1.6 GB of tables), 32 768 envs, dataset switch at every episode — where no oracle run is
+    affordable: size-independent properties of `MultiDatasetTradingEnv` semantics
+    (environments.py:365-400) and of `_get_obs` (:152-160).
+      * every window row's static columns are the rows idx-W+1..idx of the env's OWN dataset;
+      * idx - start_idx == step for running envs;
+      * dataset picks are "uniform among the least used" (:383-388) == every dataset exactly
+        once per round of D picks: over 2 rounds of short episodes each env's picks 1..D-1 are
+        distinct and picks D..2D-1 are a permutation of all D datasets (pick 0, the constructor's,
+        is consumed by no episode when the switch period is 1 — the reference's counter quirk)."""
+    import torch
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    D, T, Fs, N, W = 128, 100_000, 30, 32_768, 20
+    rng = np.random.default_rng(77)
+    data = []
+    for d in range(D):  # cheap but distinct tables: dataset d, row t, column c are recoverable
+        base = rng.normal(0, 1, (T, 1)).astype(np.float32)
+        feat = base + np.arange(Fs, dtype=np.float32)[None, :] * 0.25 + np.float32(d)
+        close = 100.0 * np.exp(np.cumsum(rng.normal(0, 1e-3, T)))
+        data.append((feat, close))
+    env = BatchedTradingEnv(data, num_envs=N, max_episode_duration=8, seed=21, output="torch",
+                            episodes_between_dataset_switch=1, **C3)
+    obs, _ = env.reset()
+    dev = obs.device
+    sample = torch.from_numpy(np.sort(rng.choice(N, 1536, replace=False))).to(dev)
+    sample_h = sample.cpu().numpy()
+    acts = torch.randint(-1, 3, (16, N), dtype=torch.int32, device=dev)
+    picks = [[] for _ in sample_h]            # datasets per episode of the sampled envs
+    last_episode = np.zeros(len(sample_h), np.int64)
+    steps = 8 * (2 * D + 2)
+    for k in range(steps):
+        obs, reward, term, trunc, info = env.step(acts[k % 16])
+        ep = env.state("episode")[sample_h]
+        ds = env.state("dataset_index")[sample_h]
+        for j in np.nonzero(ep != last_episode)[0]:
+            picks[j].append(int(ds[j]))
+        last_episode = ep
+        if k % 257 == 0 or k == steps - 1:
+            idx, start, step = (env.state(n) for n in ("idx", "start_idx", "step"))
+            need = env.state("needs_reset")
+            run = need == 0
+            np.testing.assert_array_equal((idx - start)[run], step[run])
+            o = obs[sample].cpu().numpy()
+            for j in range(0, len(sample_h), 7):
+                e = sample_h[j]
+                rows = data[ds[j]][0][idx[e] - W + 1: idx[e] + 1]
+                np.testing.assert_array_equal(o[j, :, :Fs], rows, err_msg=f"step {k} env {e}")
+    n_ok = 0
+    for p in picks:
+        if len(p) < 2 * D:
+            continue
+        first, second = p[:D - 1], p[D - 1:2 * D - 1]   # picks 1..D-1, then picks D..2D-1
+        assert len(set(first)) == D - 1, "a dataset was visited twice within its first round"
+        assert sorted(second) == list(range(D)), "the second round is not a permutation"
+        n_ok += 1
+    assert n_ok > len(picks) * 0.9
+    env.close()
