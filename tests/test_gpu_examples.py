@@ -27,3 +27,11 @@ def test_single_env_dropin_example(capsys):
     assert set(metrics) == {"Market Return", "Portfolio Return", "Position Changes", "Episode Length"}
     assert metrics["Episode Length"] == 500
     assert "Market Return" in capsys.readouterr().out
+
+
+def test_vectorized_custom_reward_example(capsys):
+    import vectorized_custom_reward
+    mean = vectorized_custom_reward.main(envs=512, steps=150)
+    assert np.isfinite(mean)
+    out = capsys.readouterr().out
+    assert "Position Changes" in out and "data_volume" in out
