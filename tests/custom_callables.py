@@ -22,5 +22,12 @@ def reward_simple_return_minus_turnover(history):
     return ret - 1e-4 * turnover
 
 
+def reward_log_return_example(history):
+    """The reward function of the reference's vectorised example and customization docs
+    (examples/example_vectorized_environment.py:39-40, docs/source/customization.rst:13-14)."""
+    return np.log(history["portfolio_valuation", -1] / history["portfolio_valuation", -2])
+
+
 DYNAMIC = {"dyn_valuation_ratio": dyn_valuation_ratio, "dyn_exposure_change": dyn_exposure_change}
-REWARD = {"reward_simple_return_minus_turnover": reward_simple_return_minus_turnover}
+REWARD = {"reward_simple_return_minus_turnover": reward_simple_return_minus_turnover,
+          "reward_log_return_example": reward_log_return_example}

@@ -456,6 +456,74 @@ def custom_callables_trace():
          "History; same env object across episodes (in-place dynamic columns persist)")
 
 
+def vector_example_fixture():
+    """hostcb_vector_example.npz: the reference's VECTORISED example
+    (examples/example_vectorized_environment.py:39-62: `gym.make_vec("TradingEnv", num_envs=3,
+    windows=5, positions=[-1 .. 2], initial_position=0, fees, borrow rate, reward_function=...)`)
+    as three reference env objects driven with the next-step convention, on a synthetic frame with
+    the example's five feature recipes — plus the `info` dict (`history[-1]`, environments.py:272)
+    of every call: its key list and every value (dates as int64 ns).  Episodes are bounded
+    (max_episode_duration=40; the example runs 'max') so that several resets are covered."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import custom_callables as cc
+    rng = np.random.default_rng(31337)
+    T = 400
+    close = 100.0 * np.exp(np.cumsum(rng.normal(0, 8e-3, T)))
+    df = pd.DataFrame({"open": close * (1 + rng.normal(0, 2e-3, T)), "high": close * 1.006,
+                       "low": close * 0.994, "close": close, "volume": rng.uniform(10, 500, T)},
+                      index=pd.date_range("2019-01-01", periods=T, freq="30min"))
+    df["feature_close"] = df["close"].pct_change()        # the example's recipes (:30-34)
+    df["feature_open"] = df["open"] / df["close"]
+    df["feature_high"] = df["high"] / df["close"]
+    df["feature_low"] = df["low"] / df["close"]
+    df["feature_volume"] = df["volume"] / df["volume"].rolling(48).max()
+    df.dropna(inplace=True)
+    feat = np.asarray(df[[c for c in df.columns if "feature" in c]], np.float32)
+    cfg = base_cfg(positions=[-1, -0.5, 0, 0.5, 1, 1.5, 2], windows=5, initial_position=0,
+                   trading_fees=0.01 / 100, borrow_interest_rate=0.0003 / 100,
+                   portfolio_initial_value=1000, max_episode_duration=40,
+                   reward_function=["custom", "reward_log_return_example"])
+    infos = []
+
+    def make(e):
+        env = TradingEnv(df=df, name="BTCUSD", reward_function=cc.reward_log_return_example,
+                         **ref_kwargs(cfg))
+        real_step, real_reset = env.step, env.reset
+
+        def step(a=None):
+            out = real_step(a)
+            infos.append(dict(out[4]))
+            return out
+
+        def reset(*a, **k):
+            out = real_reset(*a, **k)
+            infos.append(dict(out[1]))
+            return out
+        env.step, env.reset = step, reset
+        return env
+    n_envs, n_calls = 3, 150
+    rec = run_trace(make, cfg["positions"], n_envs=n_envs, n_calls=n_calls, action_rng=rng, seed_base=2468)
+    assert len(infos) == n_envs * n_calls
+    keys = list(infos[0])
+    assert all(list(i) == keys for i in infos)
+    rec["info_keys"] = np.array(keys)
+    for key in keys:  # run_trace goes env by env: infos[e * n_calls + k]
+        col = [infos[e * n_calls + k][key] for k in range(n_calls) for e in range(n_envs)]
+        if key == "date":
+            arr = np.array(col, dtype="datetime64[ns]").astype(np.int64)
+        elif key == "position_index":  # None for step(None) and for the reset row's int
+            arr = np.array([-1 if v is None else int(v) for v in col], np.int64)
+        else:
+            arr = np.array(col, dtype=np.float64)
+        rec[f"info_{key}"] = arr.reshape(n_calls, n_envs)
+    for c in ("open", "high", "low", "volume"):
+        rec[f"df_{c}"] = df[c].to_numpy(np.float64)
+    rec["df_index_ns"] = df.index.values.astype("datetime64[ns]").astype(np.int64)
+    save("hostcb_vector_example", cfg, [(feat, df["close"].to_numpy(np.float64))], rec,
+         "the reference's vectorised example: its constructor arguments and Python reward function, "
+         "three env objects, every call's info dict")
+
+
 def metrics_fixture():
     """hostcb_metrics.npz: what `get_metrics()` returns at the end of each episode of one
     reference env (the two built-in percentage strings, environments.py:279-285, plus two
@@ -577,6 +645,9 @@ def staging_fixture():
 
 
 if __name__ == "__main__":
+    if "--only-vector" in sys.argv:
+        vector_example_fixture()
+        sys.exit(0)
     if "--only-custom" in sys.argv:
         custom_callables_trace()
         metrics_fixture()
@@ -586,6 +657,7 @@ if __name__ == "__main__":
     main()
     portfolio_vectors()
     custom_callables_trace()
+    vector_example_fixture()
     metrics_fixture()
     history_fixture()
     staging_fixture()
