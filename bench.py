@@ -404,7 +404,19 @@ def main():
         from gym_trading_env_amd.distributed import ReturnGather, ReturnPipeline
         if any(m in ("step", "step-overlap") for m in modes):
             from gym_trading_env_amd.distributed import NativeReturnGather
-            comm = NativeReturnGather(env, with_obs=args.gather_obs, mode=1)  # libgte's own communicator
+            try:
+                comm = NativeReturnGather(env, with_obs=args.gather_obs, mode=1)  # libgte's own communicator
+                ok = torch.ones(1, device=dev)
+            except Exception as e:  # noqa: BLE001 - RCCL not loadable / communicator refused
+                print(f"[bench] rank {rank}: libgte's RCCL communicator unavailable ({e!r}); "
+                      "gathering through torch.distributed instead", file=sys.stderr)
+                comm, ok = None, torch.zeros(1, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank takes the same path
+            if float(ok) == 0.0:
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                modes = [("torch-step" if m == "step" else m) for m in modes if m != "step-overlap"]
         returns = ReturnGather(N, dev, obs_shape=env.obs_shape if args.gather_obs else None,
                                depth=depth, block=block)
         returns1 = ReturnGather(N, dev)  # torch-step: plain synchronous gather

@@ -263,6 +263,25 @@ __global__ __launch_bounds__(256, 4) void gte_rollout_resident_kernel(const Para
     double pv = 0.0;
     phase_a<MODE_STEP>(p, e0, active, lane, job, nullptr, /*compact=*/k == r.K - 1, &pv, &s, &a);
     if (r.valuation && active) r.valuation[(int64_t)k * p0.N + e0] = pv;
+    // An env that re-anchors (reset, dataset switch) will have its window refilled from the
+    // table when this job is published, one step from now, by waves 1-3 — a read that misses
+    // every cache while the chip is saturated with observation stores, stalling the workgroup.
+    // This wave is a step ahead with time to spare: it touches those rows now (whole wave, one
+    // env at a time, results discarded) so that the refill finds them in this CU's L1 / L2.
+    if (k > 0 && r.obs) {
+      const bool inc = (uint64_t)job.src == prev_src + (uint64_t)p0.Fobs * 4u &&
+                       job.n_zero == (prev_nz > 0 ? prev_nz - 1 : 0);
+      unsigned long long m = __ballot(active && (job.flags & 1) && !inc);
+      float4_t sink = (float4_t)0.0f;
+      while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const uint64_t src = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)((uint64_t)job.src >> 32), l) << 32) |
+                             (uint32_t)__builtin_amdgcn_readlane((int)(uint64_t)job.src, l);
+        for (uint32_t q = (uint32_t)lane; q < VL; q += 64u) sink += load_global<float4_t>(src, (int64_t)q);
+      }
+      asm volatile("" ::"v"(sink));  // keep the loads
+    }
   };
   // wave 0 hands the job of the step about to be emitted to the workgroup.  An env whose window
   // moved on by exactly one row keeps its LDS rows; anything else (first step, reset, dataset

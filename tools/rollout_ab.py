@@ -15,6 +15,9 @@ def main():
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--k", type=int, default=128)
     ap.add_argument("--reps", type=int, default=6)
+    ap.add_argument("--warm", type=int, default=50, help="single steps before the rollouts")
+    ap.add_argument("--desync", action="store_true", help="spread the episode phases first")
+    ap.add_argument("--reuse", action="store_true", help="write every rollout into the same output tensors")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     import torch
@@ -32,16 +35,20 @@ def main():
         e = BatchedTradingEnv(data if D > 1 else data[0], num_envs=N, seed=1, output="torch", **kw,
                               **bench.env_kwargs(wl))
         e.reset()
-        for i in range(50):
+        if a.desync:
+            bench.desynchronise(e, acts, wl["max_episode_duration"])
+        for i in range(a.warm):
             e.step(acts[i % a.k])
         envs[name] = e
     out = torch.empty((a.k, N) + envs[a.variants[0].split("=")[0]].obs_shape, dtype=torch.float32, device=dev)
     print("obs buffer at 0x%x" % out.data_ptr())
     del out
+    outs = {}
     for rep in range(a.reps):
         for name, e in envs.items():
             e.timer_start()
-            e.rollout(acts, keep_obs=True)
+            o = e.rollout(acts, keep_obs=True, out=outs.get(name) if a.reuse else None)
+            outs[name] = o
             print(f"rep {rep} {name:10s} {e.timer_stop() * 1e3 / a.k:7.2f} us/step", flush=True)
     for e in envs.values():
         e.close()

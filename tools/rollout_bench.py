@@ -19,14 +19,18 @@ def main():
     ap.add_argument("--envs", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--affinity", type=int, default=0, help="L2-affinity period (0 default, -1 off)")
+    ap.add_argument("--desync", action="store_true",
+                    help="spread the episode phases first (bench.desynchronise): ~N/500 envs end in "
+                         "every step instead of all of them every 500 steps")
     a = ap.parse_args()
     import torch
     from gym_trading_env_amd.batched import BatchedTradingEnv
     wl = bench.WORKLOADS[a.workload]
     N = a.envs or wl["envs"]
-    feat, close = bench.synthetic_dataset(0, wl["T"], wl["n_static"])
+    D = wl["n_datasets"]  # config 5: 128 resident datasets, a dataset switch at every episode
+    data = [bench.synthetic_dataset(d, wl["T"], wl["n_static"]) for d in range(D)]
     dev = torch.device("cuda", 0)
-    env = BatchedTradingEnv((feat, close), num_envs=N, seed=1, output="torch",
+    env = BatchedTradingEnv(data if D > 1 else data[0], num_envs=N, seed=1, output="torch",
                             kernel_variant=a.variant, affinity_period=a.affinity,
                             **bench.env_kwargs(wl))
     env.reset()
@@ -34,6 +38,8 @@ def main():
     b_alg = bench.algorithmic_bytes(W, wl["n_static"] + 2, wl["n_static"], 2)
     Kmax = max(a.k)
     acts = torch.randint(0, 3, (Kmax, N), dtype=torch.int32, device=dev)
+    if a.desync:
+        bench.desynchronise(env, acts, wl["max_episode_duration"])
     for i in range(100):
         env.step(acts[i % Kmax])
 
