@@ -32,15 +32,31 @@ def __getattr__(name):
 
 def register_gymnasium_ids():
     """Register 'TradingEnv' and 'MultiDatasetTradingEnv' like the reference's
-    __init__.py:3-14 (same ids and flags).  No-op when gymnasium is not installed."""
+    __init__.py:3-14 (same ids and flags), plus — where Gymnasium supports it — a vector entry
+    point so that the reference's `gym.make_vec("TradingEnv", num_envs=N, ...)`
+    (examples/example_vectorized_environment.py:44) yields ONE BatchedTradingEnv.  No-op when
+    gymnasium is not installed (it is not, in the build and test images: this wiring is written
+    against Gymnasium's documented API and is unpinned)."""
     try:
         from gymnasium.envs.registration import register, registry
     except Exception:
         return False
     from . import envs
+
+    def make_batch(num_envs=1, **kwargs):  # gym.make_vec(id, num_envs=N, ...) -> one batched env
+        from .batched import BatchedTradingEnv
+        if "dataset_dir" in kwargs:
+            return BatchedTradingEnv.from_dataset_dir(kwargs.pop("dataset_dir"), num_envs, **kwargs)
+        return BatchedTradingEnv(kwargs.pop("df"), num_envs, **kwargs)
+
     for env_id, cls in (("TradingEnv", envs.TradingEnv),
                         ("MultiDatasetTradingEnv", envs.MultiDatasetTradingEnv)):
-        if env_id not in registry:
+        if env_id in registry:
+            continue
+        try:  # Gymnasium >= 1.0: `gym.make_vec` builds the HBM-resident batch, not N Python envs
+            register(id=env_id, entry_point=cls, vector_entry_point=make_batch,
+                     disable_env_checker=True, order_enforce=False)
+        except TypeError:  # older Gymnasium: no vector entry point
             register(id=env_id, entry_point=cls, disable_env_checker=True, order_enforce=False)
     return True
 

@@ -252,3 +252,41 @@ def test_stage_dataframe_equals_the_reference_set_df():
     for j, c in enumerate(ref_info):
         np.testing.assert_array_equal(np.asarray(s.info_array[:, s.info_columns.index(c)], np.float64),
                                       z["info_array"][:, j])
+
+
+@pytest.mark.parametrize("modern", [True, False])
+def test_gymnasium_registration_with_a_stand_in(monkeypatch, modern):
+    """register_gymnasium_ids() (the reference's __init__.py:3-14: same ids, same flags) against
+    an in-memory stand-in of `gymnasium.envs.registration` — gymnasium itself is not installed
+    here.  Gymnasium >= 1.0 also gets a vector entry point (gym.make_vec -> one batched env);
+    an older register() without that keyword is called the reference's way."""
+    import sys
+    import types
+    import gym_trading_env_amd as gte
+    calls = []
+
+    def register_modern(id, entry_point=None, vector_entry_point=None, disable_env_checker=False,
+                        order_enforce=True, **kw):
+        calls.append(dict(id=id, entry_point=entry_point, vector_entry_point=vector_entry_point,
+                          disable_env_checker=disable_env_checker, order_enforce=order_enforce))
+
+    def register_old(id, entry_point=None, disable_env_checker=False, order_enforce=True):
+        calls.append(dict(id=id, entry_point=entry_point, vector_entry_point=None,
+                          disable_env_checker=disable_env_checker, order_enforce=order_enforce))
+
+    reg = types.ModuleType("gymnasium.envs.registration")
+    reg.register = register_modern if modern else register_old
+    reg.registry = {}
+    gym = types.ModuleType("gymnasium")
+    envs_mod = types.ModuleType("gymnasium.envs")
+    envs_mod.registration = reg
+    gym.envs = envs_mod
+    for name, mod in (("gymnasium", gym), ("gymnasium.envs", envs_mod),
+                      ("gymnasium.envs.registration", reg)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    assert gte.register_gymnasium_ids() is True
+    assert [c["id"] for c in calls] == ["TradingEnv", "MultiDatasetTradingEnv"]
+    from gym_trading_env_amd import envs
+    assert calls[0]["entry_point"] is envs.TradingEnv and calls[1]["entry_point"] is envs.MultiDatasetTradingEnv
+    assert all(c["disable_env_checker"] is True and c["order_enforce"] is False for c in calls)
+    assert all((c["vector_entry_point"] is not None) == modern for c in calls)
