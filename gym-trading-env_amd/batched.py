@@ -165,11 +165,11 @@ class BatchedTradingEnv(_VectorEnvBase):
         self._reward_callable = (reward_function if resolve_reward(reward_function)[0] == HOST_CALLABLE
                                  else None)
         if self._dyn_callables or self._reward_callable is not None:
+            if output != "torch":
+                raise NotImplementedError("custom reward / dynamic-feature callables in the batch are "
+                                          "evaluated on the device: use output='torch'")
             if autoreset == "same_step":
-                raise NotImplementedError(
-                    "custom reward / dynamic-feature callables need autoreset='next_step' or None: in "
-                    "same-step mode the terminal History row an env's callable would see is replaced "
-                    "by the reset row inside the launch")
+                final_obs = True  # the terminal History row of an env that ends comes from its terminal record
             log_steps = max(int(log_steps), 2)  # the callables read h[..., -1] and h[..., -2]
         raw = list(df) if isinstance(df, (list, tuple)) and not (
             isinstance(df, tuple) and len(df) in (2, 4) and hasattr(df[0], "shape")) else [df]
@@ -210,7 +210,7 @@ class BatchedTradingEnv(_VectorEnvBase):
         for d, s in enumerate(self.datasets):
             self.upload_dataset(d, s)
 
-        self._final_view, self._final_epoch = _abi.GteStateView(), -1
+        self._final_view, self._final_epoch, self._final_tensors = _abi.GteStateView(), -1, {}
         self._logv, self._log_tensors, self._pos_table = _abi.GteLogView(), {}, None
         self._state = _abi.GteStateView()
         self._epoch, self._state_epoch = 0, -1  # state snapshots are taken lazily
@@ -449,6 +449,59 @@ class BatchedTradingEnv(_VectorEnvBase):
         return self._to_host(getattr(self._final_view, name), _NP[_abi.STATE_DTYPES[name]],
                              self.num_envs)
 
+    def _final_tensor(self, name):
+        """torch view [N] of one array of the terminal records (`gte_get_final_state`, refreshed
+        once per step)."""
+        torch = self._torch
+        if self._final_epoch != self._epoch:
+            _abi.check(self._lib, self._lib.gte_get_final_state(self._h, C.byref(self._final_view)))
+            self._final_epoch = self._epoch
+        t = self._final_tensors.get(name)
+        if t is None:
+            dt = _abi.STATE_DTYPES[name]
+
+            class _Raw:
+                __cuda_array_interface__ = {
+                    "shape": (self.num_envs,), "typestr": "<i4" if dt == "int32" else "<f8",
+                    "data": (int(getattr(self._final_view, name)), False), "version": 2, "strides": None}
+            t = torch.as_tensor(_Raw(), device=self._t["obs"].device)
+            self._final_tensors[name] = t
+        return t
+
+    def _overlay(self, v, name, only=None):
+        """`v` (a History column at the newest row, [N]) with the entries of the envs that ended
+        in the last step replaced by their TERMINAL row's value (same-step mode, BatchedHistory
+        terminal view); `only`: restrict to these envs."""
+        torch = self._torch
+        ended = self._t["terminated"] | self._t["truncated"]
+        if only is not None:
+            ended = ended & only
+        f = self._final_tensor
+        if name in ("idx", "step", "position_index", "dataset_index", "portfolio_valuation",
+                    "real_position"):
+            t = f(name)
+        elif name == "position":
+            t = self._positions_table()[f("position_index").long()]
+        elif name == "reward":
+            return v  # the step's reward already is the terminal step's
+        elif name == "date" or name.startswith("data_"):
+            t = self._dataset_column(name, f("dataset_index"), f("idx"))
+            if not isinstance(t, torch.Tensor):  # host column (dates, objects)
+                m = ended.cpu().numpy()
+                out = np.array(v, copy=True)
+                out[m] = np.asarray(t)[m]
+                return out
+        elif name.startswith("portfolio_distribution_"):
+            k = name[len("portfolio_distribution_"):]
+            if k in ("interest_asset", "interest_fiat"):
+                t = f(k)
+            else:
+                src = f("asset" if k.endswith("asset") else "fiat")
+                t = (-src if k.startswith("borrowed") else src).clamp_min(0.0)
+        else:
+            return v
+        return torch.where(ended, t.to(v.dtype), v)
+
     def _final_entries(self) -> dict:
         """Gymnasium's `final_observation` / `final_info` (+ masks) for the envs that ended in
         the last step: the observation and the History row `TradingEnv.step` returned for them
@@ -548,11 +601,12 @@ class BatchedTradingEnv(_VectorEnvBase):
         else:
             raise NotImplementedError("assigning log rewards needs output='torch'")
 
-    def batched_history(self):
+    def batched_history(self, terminal: bool = False):
         """The `BatchedHistory` of the batch right now (needs ``log_steps``): what custom reward /
-        dynamic-feature / metric callables receive."""
+        dynamic-feature / metric callables receive.  terminal=True: the same-step view in which
+        envs that just ended show their terminal row as the newest one."""
         from .batched_history import BatchedHistory
-        return BatchedHistory(self)
+        return BatchedHistory(self, terminal=terminal)
 
     def _apply_callables(self, after_reset: bool):
         """The user's own `reward_function` / `dynamic_feature_functions` (any callable that is
@@ -568,22 +622,42 @@ class BatchedTradingEnv(_VectorEnvBase):
             raise NotImplementedError("custom callables in the batch need output='torch'")
         from .device_array import to_tensor
         dev = self._t["obs"].device
-        h = self.batched_history()
+        N = self.num_envs
+        same_step = self.cfg.autoreset == _abi.AUTORESET_SAME_STEP and not after_reset
+        # same-step mode: an env that ended shows the callable its TERMINAL row (the log row of
+        # this step already holds the state after the in-launch reset, which is what the NEXT
+        # step's h[..., -2] must be)
+        h = self.batched_history(terminal=same_step)
+        ended = (self._t["terminated"] | self._t["truncated"]) if same_step else None
+        newest = (h._rows - 1) % h._L
         if self._reward_callable is not None and not after_reset:
             r = to_tensor(self._reward_callable(h), dev, torch.float64)
-            if r.shape != (self.num_envs,):
+            if r.shape != (N,):
                 raise ValueError(f"reward_function must return one value per env, got shape {tuple(r.shape)}")
-            newest = (h._rows - 1) % h._L
-            skip = self._t["terminated"] | (self._log_tensor("step")[newest] == 0)
-            r = torch.where(skip, torch.zeros_like(r), r)
+            reset_row = self._log_tensor("step")[newest] == 0
+            if same_step:
+                reset_row = reset_row & ~ended  # an ended env's reset row is overlaid by its terminal row
+            r = torch.where(self._t["terminated"] | reset_row, torch.zeros_like(r), r)
             self._t["reward64"].copy_(r)
             self._t["reward"].copy_(r.to(torch.float32))
-            h["reward", -1] = r
+            self._set_log_reward(r)
         if self._dyn_callables:
-            vals = torch.zeros((self.num_envs, self.cfg.n_dyn), dtype=torch.float32, device=dev)
+            vals = torch.zeros((N, self.cfg.n_dyn), dtype=torch.float32, device=dev)
             mask = 0
+            fresh = self.batched_history() if (same_step and bool(ended.any())) else None
             for i, fn in self._dyn_callables:
-                vals[:, i] = to_tensor(fn(h), dev, torch.float32)
+                v = to_tensor(fn(h), dev, torch.float32)
+                if fresh is not None:
+                    # the terminal observation shows the feature of the terminal row, the returned
+                    # observation the one of the reset row (reset() evaluates it on a 1-row History)
+                    col = self.datasets[0].n_static + i
+                    fo = self._t["final_obs"]
+                    if fo.dim() == 3:
+                        fo[ended, -1, col] = v[ended]
+                    else:  # windows=None: the observation is one row
+                        fo[ended, col] = v[ended]
+                    v = torch.where(ended, to_tensor(fn(fresh), dev, torch.float32), v)
+                vals[:, i] = v
                 mask |= 1 << i
             self._keep_dyn = vals
             _abi.check(self._lib, self._lib.gte_set_dynamic_features(

@@ -45,10 +45,15 @@ def history_columns(env) -> list:
 
 
 class BatchedHistory:
-    def __init__(self, env):
+    def __init__(self, env, terminal: bool = False):
+        """terminal=True (same-step auto-reset): for the envs whose episode ended in the last
+        step the NEWEST row is the terminal row `TradingEnv.step` logged (environments.py:253-264)
+        — taken from the terminal records, because the log row of that step already holds the
+        state after the in-launch reset; every other row and env reads the log as usual."""
         if not env.cfg.log_steps:
             raise ValueError("BatchedHistory needs log_steps > 0 (it reads the device trajectory log)")
         self._env = env
+        self._terminal = bool(terminal)
         self.columns = history_columns(env) + ["dataset_index"]
         view = env._log_view()
         self._rows, self._L = int(view.rows), int(view.L)
@@ -67,6 +72,8 @@ class BatchedHistory:
                 raise IndexError(f"index {t} is out of bounds: {self._have} rows are logged")
             return (self._rows + t) % self._L
         step = self._env._log_row("step", (self._rows - 1) % self._L, raw=True)
+        if self._terminal:
+            step = self._env._overlay(step, "step")
         back = step - t  # rows between the wanted row and the newest one
         if bool((back < 0).any()) or bool((back >= self._have).any()):
             raise IndexError(f"index {t} is outside the current episode / the {self._L} logged rows "
@@ -76,6 +83,19 @@ class BatchedHistory:
     def _column(self, name, phys):
         """Values of column `name` at physical row(s) `phys`: a scalar row, a per-env row vector
         [N] or None for every logged row, oldest first ([R, N])."""
+        v = self._log_column(name, phys)
+        if not self._terminal:
+            return v
+        e, newest = self._env, (self._rows - 1) % self._L
+        if phys is None:      # the last row of the window is the newest one
+            v = v.clone() if hasattr(v, "clone") else v.copy()
+            v[-1] = e._overlay(v[-1], name)
+            return v
+        if np.ndim(phys) == 0:
+            return e._overlay(v, name) if int(phys) == newest else v
+        return e._overlay(v, name, only=(phys == newest))
+
+    def _log_column(self, name, phys):
         e = self._env
         if name in _LOG_COLUMNS:
             return e._log_rows(name, phys, self._order())

@@ -93,8 +93,16 @@ class SB3TradingVecEnv(_Base):
         for k in ("autoreset", "final_obs", "output"):
             if k in kw:
                 raise TypeError(f"{k} is fixed by the VecEnv contract")
+        from .config import HOST_CALLABLE, resolve_dynamic_features, resolve_reward
+        custom = (resolve_reward(kw.get("reward_function", "basic_reward_function"))[0] == HOST_CALLABLE
+                  or HOST_CALLABLE in resolve_dynamic_features(
+                      kw.get("dynamic_feature_functions", ("last_position_taken", "real_position"))))
+        # a user's Python reward / dynamic-feature callable (the fork's training scripts pass one,
+        # luckymodel/envs/env.py:16-18) is evaluated on the device over a BatchedHistory: the inner
+        # env then keeps torch outputs and this adapter copies them to the host arrays SB3 wants
+        self._torch_inner = bool(custom)
         self.env = BatchedTradingEnv(df, num_envs=num_envs, autoreset="same_step", final_obs=True,
-                                     output="numpy", **kw)
+                                     output="torch" if custom else "numpy", **kw)
         self.num_envs = int(num_envs)
         self.observation_space = spaces.Box(-np.inf, np.inf, shape=self.env.obs_shape)
         self.action_space = spaces.Discrete(len(self.env.positions))
@@ -108,15 +116,19 @@ class SB3TradingVecEnv(_Base):
             _Base.__init__(self, self.num_envs, self.observation_space, self.action_space)
 
     # -- VecEnv API --------------------------------------------------------------------------
+    def _host(self, x):
+        return x.cpu().numpy() if self._torch_inner else x
+
     def reset(self):
         obs, _ = self.env.reset()
-        return obs
+        return self._host(obs)
 
     def step_async(self, actions):
         self._actions = np.asarray(actions, dtype=np.int32).reshape(self.num_envs)
 
     def step_wait(self):
         obs, reward, terminated, truncated, info = self.env.step(self._actions)
+        obs, reward, terminated, truncated = (self._host(x) for x in (obs, reward, terminated, truncated))
         dones = terminated | truncated
         self._columns.cols = {k: info[k] for k in self.info_keys}
         infos = self._infos
@@ -125,7 +137,7 @@ class SB3TradingVecEnv(_Base):
         self._dirty = []
         if dones.any():
             ids, last = self.env.final_observations()
-            ids = ids.tolist()
+            ids, last = ids.tolist(), self._host(last)
             for e, o in zip(ids, last):
                 d = infos[e]
                 dict.__setitem__(d, "terminal_observation", o)

@@ -192,8 +192,8 @@ def test_functions_named_like_the_defaults_are_the_users_code():
         assert (r[reset_row] == 0).all() and (r[~reset_row & ~term.cpu().numpy()] == 0.25).all()
         assert (obs.cpu().numpy()[:, -1] == 7.0).all()
     assert reset_row.any() or True
-    with pytest.raises(NotImplementedError, match="same-step|next_step"):
-        gte.BatchedTradingEnv(df, 4, reward_function=batch_reward, autoreset="same_step")
+    with pytest.raises(NotImplementedError, match="output='torch'"):  # evaluated on the device
+        gte.BatchedTradingEnv(df, 4, reward_function=batch_reward, output="numpy")
     env.close()
 
 
@@ -344,3 +344,51 @@ def test_batch_replays_the_reference_vector_example_fixture():
                 np.testing.assert_allclose(np.asarray(got, np.float64), ref, rtol=1e-12, atol=1e-14,
                                            err_msg=f"call {k} {key}")
     env.close()
+
+
+def test_sb3_vecenv_with_the_forks_python_reward_function():
+    """The fork's training scripts give SB3 a Python reward function
+    (luckymodel/envs/env.py:16-18: np.clip(np.log(p_t / p_t-1), -0.002, 0.005)) and custom-named
+    re-implementations of the two default dynamic features.  SB3TradingVecEnv (same-step
+    auto-reset, `terminal_observation`) takes them as they are; results equal the device enum
+    `("clipped_log_return", 1, -0.002, 0.005)` / the device features."""
+    import gym_trading_env_amd as gte
+
+    def reward_function(history):  # verbatim from the fork
+        log_return = np.log(history["portfolio_valuation", -1] / history["portfolio_valuation", -2])  # log (p_t / p_t-1 )
+        return np.clip(log_return, -0.002, 0.005)
+
+    def dynamic_feature_last_position_taken(history):
+        return history['position', -1]
+
+    def dynamic_feature_real_position(history):
+        return history['real_position', -1]
+
+    feat, close = _walk(44, 500, 4, sigma=3e-2, drift=-1e-3)
+    df = make_df(feat, close)
+    kw = dict(positions=[-1, 0, 1], windows=6, trading_fees=1e-3, borrow_interest_rate=1e-4,
+              max_episode_duration=15, seed=12)
+    N = 300
+    custom = gte.SB3TradingVecEnv(df, N, reward_function=reward_function,
+                                  dynamic_feature_functions=[dynamic_feature_last_position_taken,
+                                                             dynamic_feature_real_position], **kw)
+    builtin = gte.SB3TradingVecEnv(df, N, reward_function=("clipped_log_return", 1.0, -0.002, 0.005), **kw)
+    assert custom.env.output == "torch" and builtin.env.output == "numpy"
+    np.testing.assert_array_equal(custom.reset(), builtin.reset())
+    rng = np.random.default_rng(3)
+    ends = 0
+    for k in range(60):
+        a = rng.integers(0, 3, N)
+        o1, r1, d1, i1 = custom.step(a)
+        o2, r2, d2, i2 = builtin.step(a)
+        np.testing.assert_array_equal(o1, o2, err_msg=f"step {k}")
+        np.testing.assert_array_equal(d1, d2)
+        np.testing.assert_allclose(r1, r2, rtol=1e-6, atol=1e-12)
+        for e in np.nonzero(d1)[0]:
+            np.testing.assert_array_equal(i1[e]["terminal_observation"], i2[e]["terminal_observation"],
+                                          err_msg=f"step {k} env {e}")
+            assert i1[e]["TimeLimit.truncated"] == i2[e]["TimeLimit.truncated"]
+            assert i1[e]["portfolio_valuation"] == i2[e]["portfolio_valuation"]
+        ends += int(d1.sum())
+    assert ends > N
+    custom.close(); builtin.close()
