@@ -671,12 +671,16 @@ class BatchedTradingEnv(_VectorEnvBase):
             raise ValueError("add_metric needs log_steps > 0 (the History comes from the device log)")
         self.log_metrics.append({"name": name, "function": function})
 
-    def history(self, env_id: int):
+    def history(self, env_id: int, finished: bool = False):
         """The current (or just finished) episode of one env as a `History` with the
         reference's columns (environments.py:186-197, 253-264: idx, step, date, position_index,
         position, real_position, data_*, portfolio_valuation, portfolio_distribution_*, reward),
         rebuilt from the device trajectory log.  Episodes longer than ``log_steps`` are
-        truncated at the front."""
+        truncated at the front.
+
+        finished=True (same-step auto-reset with ``final_obs``, right after the step in which the
+        env ended): the episode that just FINISHED — its rows from the log plus the terminal row
+        from the env's terminal record (that step's log row already describes the new episode)."""
         from .history import History
         L = int(self.cfg.log_steps)
         if not L:
@@ -692,6 +696,22 @@ class BatchedTradingEnv(_VectorEnvBase):
         _abi.check(self._lib, self._lib.gte_read_log_portfolio(
             self._h, int(env_id), L, *(b.ctypes.data for b in port.values()), C.byref(n)))
         n = n.value
+        if finished:
+            if not self.cfg.final_obs:
+                raise ValueError("history(finished=True) needs autoreset='same_step', final_obs=True")
+            if not (bufs["flags"][n - 1] & 3):
+                raise ValueError(f"env {env_id} did not end in the last step")
+            # drop the newest row (the reset row of the next episode) and put the terminal row,
+            # with that step's reward, in its place
+            e = int(env_id)
+            fs = self.final_state
+            for key, name in (("idx", "idx"), ("step", "step"), ("pos", "position_index"),
+                              ("ds", "dataset_index"), ("pv", "portfolio_valuation"),
+                              ("rp", "real_position")):
+                bufs[key][n - 1] = fs(name)[e]
+            for key, name in (("asset", "asset"), ("fiat", "fiat"), ("ia", "interest_asset"),
+                              ("ifi", "interest_fiat")):
+                port[key][n - 1] = fs(name)[e]
         step = bufs["step"][:n]
         # the episode = the last run of rows whose step counts 0, 1, 2, ...
         start = n - 1
@@ -749,6 +769,7 @@ class BatchedTradingEnv(_VectorEnvBase):
         same-step auto-reset and ``final_obs`` the terminal records are used)."""
         ids = self.terminal_ids() if env_ids is None else np.asarray(env_ids, dtype=np.int64)
         state = self.final_state if (self.cfg.final_obs and env_ids is None) else self.state
+        use_final = bool(self.cfg.final_obs and env_ids is None)
         ds, idx, start = (state(k)[ids] for k in ("dataset_index", "idx", "start_idx"))
         pv = state("portfolio_valuation")[ids]
         close_now = np.asarray(self._dataset_column("data_close", ds, idx), dtype=np.float64)
@@ -760,7 +781,7 @@ class BatchedTradingEnv(_VectorEnvBase):
                "Market Return": [f"{100 * m:5.2f}%" for m in market.tolist()],
                "Portfolio Return": [f"{100 * r:5.2f}%" for r in portfolio.tolist()]}
         if self.log_metrics:  # custom metrics over each finished env's History (:285-286)
-            hists = [self.history(int(e)) for e in ids]
+            hists = [self.history(int(e), finished=use_final) for e in ids]
             for metric in self.log_metrics:
                 out[metric["name"]] = [metric["function"](h) for h in hists]
         return out

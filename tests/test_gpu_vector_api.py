@@ -392,3 +392,48 @@ def test_sb3_vecenv_with_the_forks_python_reward_function():
         ends += int(d1.sum())
     assert ends > N
     custom.close(); builtin.close()
+
+
+def test_same_step_finished_episode_history_and_custom_metrics():
+    """Same-step auto-reset (SB3's mode) with a device log: `history(e, finished=True)` is the
+    episode that just ended — terminal row included — and `episode_metrics()` evaluates
+    `add_metric` functions on it (environments.py:274-286); checked against a twin batch that does
+    not reset (same first episodes)."""
+    import gym_trading_env_amd as gte
+    feat, close = _walk(55, 300, 3, sigma=2e-2)
+    df = make_df(feat, close)
+    kw = dict(positions=[-1, 0, 1], windows=3, trading_fees=1e-3, max_episode_duration=9, seed=2,
+              output="numpy", log_steps=32)
+    N = 64
+    env = gte.BatchedTradingEnv(df, N, autoreset="same_step", final_obs=True, **kw)
+    twin = gte.BatchedTradingEnv(df, N, autoreset=None, **kw)
+    for e in (env, twin):
+        e.add_metric("Position Changes", lambda h: int(np.sum(np.diff(h["position"]) != 0)))
+        e.add_metric("Episode Length", lambda h: len(h["position"]))
+    env.reset(); twin.reset()
+    rng = np.random.default_rng(9)
+    first = np.ones(N, bool)
+    checked = 0
+    for k in range(10):
+        a = rng.integers(0, 3, N).astype(np.int32)
+        _, _, term, trunc, _ = env.step(a)
+        twin.step(a)
+        ended = term | trunc
+        if ended.any():
+            m = env.episode_metrics()
+            for j, e in enumerate(m["env_ids"]):
+                if not first[e]:
+                    continue
+                hf, ht = env.history(int(e), finished=True), twin.history(int(e))
+                assert len(hf) == len(ht) == m["Episode Length"][j]
+                for col in ("idx", "step", "position", "portfolio_valuation", "reward", "data_close",
+                            "portfolio_distribution_fiat"):
+                    np.testing.assert_array_equal(np.asarray(hf[col], np.float64), np.asarray(ht[col], np.float64), err_msg=col)
+                assert m["Position Changes"][j] == int(np.sum(np.diff(ht["position"]) != 0))
+                assert m["Portfolio Return"][j] == f"{100 * (ht['portfolio_valuation', -1] / 1000 - 1):5.2f}%"
+                checked += 1
+        first &= ~ended
+    assert checked >= N
+    with pytest.raises(ValueError, match="did not end"):
+        env.history(int(np.nonzero(~ended)[0][0]), finished=True)
+    env.close(); twin.close()
