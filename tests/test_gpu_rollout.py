@@ -182,3 +182,44 @@ def test_rollout_argument_errors():
     out = env.rollout([[None] * 64, [1] * 64])  # None = hold, like step()
     assert out["reward"].shape == (2, 64)
     env.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_rollout_random_shapes_equal_single_steps(seed):
+    """Random window lengths (one-row LDS rings to 40 rows), row widths (1 to 40 vectors), 1-4
+    dynamic features, env counts that leave ragged workgroups, auto-reset modes, several datasets,
+    violent prices (drawdown terminations): a fused rollout — with every step's observations and
+    without — equals single steps bit for bit, and so do the steps that follow."""
+    import torch
+    rng = np.random.default_rng(7000 + seed)
+    nd = int(rng.integers(1, 5))
+    fv = int(rng.integers(1, 41))                 # vectors per row
+    Fs = 4 * fv - nd
+    if Fs < 0:
+        fv += 1
+        Fs = 4 * fv - nd
+    W = int(rng.choice([2, 3, 5, 8, 13, 20, 40]))
+    D = int(rng.choice([1, 1, 3]))
+    T = int(rng.integers(3 * W + 40, 3 * W + 400))
+    sigma = float(rng.choice([2e-3, 2e-2, 6e-2]))
+    data = [_data(9000 + 10 * seed + d, T + 7 * d, Fs, sigma=sigma)[:2] for d in range(D)]
+    kinds = [str(rng.choice(["last_position_taken", "real_position"])) for _ in range(nd)]
+    autoreset = [None, "next_step", "same_step"][int(rng.integers(3))]
+    N = int(rng.integers(1, 2500))
+    kw = dict(positions=sorted(set(np.round(rng.uniform(-2, 3, 4), 1).tolist() + [0.0])), windows=W,
+              dynamic_feature_functions=kinds, trading_fees=float(rng.choice([0, 1e-4, 1e-2])),
+              borrow_interest_rate=float(rng.choice([0, 3e-6, 1e-3])),
+              max_episode_duration=int(rng.integers(4, 30)), autoreset=autoreset,
+              episodes_between_dataset_switch=int(rng.integers(1, 3)), seed=seed)
+    a, b = _twins(data if D > 1 else data[0], N, **kw)
+    P = len(kw["positions"])
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    for K, keep in ((int(rng.integers(2, 30)), True), (int(rng.integers(2, 30)), False), (1, True)):
+        acts = torch.randint(-1, P, (K, N), dtype=torch.int32, device="cuda", generator=gen)
+        _check(a, b, acts, keep, f"seed {seed} W={W} Fobs={Fs + nd} nd={nd} N={N} K={K} {autoreset}")
+        one = torch.randint(-1, P, (N,), dtype=torch.int32, device="cuda", generator=gen)
+        for x, y in zip(a.step(one)[:4], b.step(one)[:4]):
+            np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
+    a.close()
+    b.close()
