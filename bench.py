@@ -340,7 +340,11 @@ def main():
     # Counter passes first, while this process has not touched the GPU: each is a child
     # `rocprofv3 --pmc X -- python3 bench.py --pmc-child ...` (the program itself after `--`).
     live = {}
-    if world == 1 and not args.pmc_child and not args.no_pmc:
+    profiled = ("rocprof" in os.environ.get("LD_PRELOAD", "").lower()
+                or any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ))
+    if profiled:  # this process is itself being profiled: no nested profiler runs
+        print("[bench] running under a profiler: traffic comes from profiles/hbm_traffic.json", file=sys.stderr)
+    if world == 1 and not args.pmc_child and not args.no_pmc and not profiled:
         for n in [N] + ([HBM_REGIME_ENVS] if hbm_leg else []):
             t = pmc_traffic(args, n)
             if not t:
