@@ -35,3 +35,13 @@ def test_vectorized_custom_reward_example(capsys):
     assert np.isfinite(mean)
     out = capsys.readouterr().out
     assert "Position Changes" in out and "data_volume" in out
+
+
+def test_c_abi_demo_runs(tmp_path):
+    """examples/c_abi_demo.c — the hot path and the RCCL return gather driven from plain C."""
+    import subprocess
+    from test_host_cpu import _build_c_demo
+    exe = _build_c_demo(tmp_path)
+    r = subprocess.run([exe, "2048", "120"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "c_abi_demo ok: 2048 envs x 120 steps" in r.stdout and "episode ends seen" in r.stdout

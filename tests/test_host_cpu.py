@@ -290,3 +290,27 @@ def test_gymnasium_registration_with_a_stand_in(monkeypatch, modern):
     assert calls[0]["entry_point"] is envs.TradingEnv and calls[1]["entry_point"] is envs.MultiDatasetTradingEnv
     assert all(c["disable_env_checker"] is True and c["order_enforce"] is False for c in calls)
     assert all((c["vector_entry_point"] is not None) == modern for c in calls)
+
+
+def _build_c_demo(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "c_abi_demo")
+    csrc = os.path.join(ROOT, "gym-trading-env_amd", "csrc")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_abi_demo.c"), "-L", csrc, "-lgte",
+                           f"-Wl,-rpath,{csrc}", "-lm", "-o", exe])
+    return exe
+
+
+def test_c_program_binds_the_abi_and_fails_loudly_without_a_gpu(tmp_path):
+    """examples/c_abi_demo.c: a plain C host (gcc, include/gte.h, -lgte; no Python, no torch)
+    compiles against the boundary; on a host without a gfx950 device it stops at gte_create with
+    GTE_ERR_NO_DEVICE — there is no CPU fallback to fall into."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the C demo runs for real in tests/test_gpu_examples.py")
+    exe = _build_c_demo(tmp_path)
+    r = subprocess.run([exe, "64", "5"], capture_output=True, text=True)
+    assert r.returncode == 3
+    assert "no CPU fallback" in r.stderr and "gte_create" in r.stderr
