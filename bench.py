@@ -35,10 +35,12 @@ host cores on a bounded sample of the same workload.
 
 Multi-GPU (torchrun, one rank per GPU): envs shard with no data-path collective
 except the RCCL all-gather of the returns (reward, terminated, truncated: 6 bytes
-per env and step), which is what the north star names.  `--gather-mode step` gathers
-synchronously after every step through the C ABI's own RCCL communicator
-(gte_allgather_returns); `--gather-mode block` (default) moves a --gather-every (32) step
-block at a time on RCCL's stream while the following steps run (DESIGN.md §6);
+per env and step), which is what the north star names.  `value` is measured with per-step
+returns through the C ABI's own RCCL communicator (gte_allgather_returns): synchronously after
+every step (`--gather-mode step`) or overlapping the next step (`step-overlap`), whichever a short
+probe finds faster on the node (`auto`, the default); `block` moves a --gather-every (32) step
+block at a time on RCCL's stream while the following steps run and is reported
+beside it (config.other_gather_modes);
 --gather-obs adds the observation all-gather (xGMI-bound).  Weak scaling: 65 536 envs/GPU.
 """
 from __future__ import annotations
@@ -299,15 +301,19 @@ def main():
                     help="skip the 262 144-env leg (observations streamed to HBM)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--gather-obs", action="store_true", help="also all-gather observations (N>1)")
-    ap.add_argument("--gather-mode", default="step", choices=["step", "step-overlap", "block", "torch-step"],
+    ap.add_argument("--gather-mode", default="auto",
+                    choices=["auto", "step", "step-overlap", "block", "torch-step"],
                     help="N>1, the mode `value` is measured in: 'step' = synchronous per-step "
                          "all-gather through libgte's own RCCL communicator (gte_allgather_returns, "
                          "what the north star describes); 'step-overlap' = the same on the library's "
                          "communication stream, overlapping the next step (returns one step late); "
                          "'block' = asynchronous all-gather of --gather-every step blocks "
                          "(torch.distributed); 'torch-step' = synchronous per-step through "
-                         "torch.distributed.  The other modes are measured too and reported under "
-                         "config.other_gather_modes")
+                         "torch.distributed; 'auto' (default) = the faster of the two PER-STEP forms "
+                         "'step' and 'step-overlap', decided by a short untimed probe on this node "
+                         "(synchronous gathers pay RCCL's cross-GPU latency in every step, overlapped "
+                         "ones two cross-stream events).  The other modes are measured too and "
+                         "reported under config.other_gather_modes")
     ap.add_argument("--one-gather-mode", action="store_true",
                     help="N>1: measure only --gather-mode")
     ap.add_argument("--gather-every", type=int, default=32,
@@ -378,8 +384,9 @@ def main():
 
     modes = []
     if use_dist:
-        modes = [args.gather_mode] + ([] if args.one_gather_mode else
-                                      [m for m in ("step", "step-overlap", "block") if m != args.gather_mode])
+        first = "step" if args.gather_mode == "auto" else args.gather_mode
+        modes = [first] + ([] if args.one_gather_mode and args.gather_mode != "auto" else
+                           [m for m in ("step", "step-overlap", "block") if m != first])
         if backend != "nccl":  # the library's communicator is RCCL: gloo rehearsals use torch's
             modes = [m for m in modes if m in ("block", "torch-step")] or ["block"]
     depth = max(2, args.gather_depth)
@@ -477,6 +484,17 @@ def main():
             el, ev_ms = float(t[0]), float(t[1])
         return el, ev_ms
 
+    if args.gather_mode == "auto" and "step" in modes and "step-overlap" in modes:
+        # which per-step form is faster here?  (untimed probe: a few steps of each)
+        keep = (args.warmup, args.steps)
+        args.warmup, args.steps = 3, 12
+        probe = {m: timed(m, 0)[0] for m in ("step", "step-overlap")}
+        args.warmup, args.steps = keep
+        best = min(probe, key=probe.get)
+        print(f"[bench] per-step gather probe: {probe} -> {best}", file=sys.stderr)
+        modes = [best] + [m for m in modes if m != best]
+        if args.one_gather_mode:
+            modes = modes[:1]
     episodes0 = int(env.state("episode").sum())
     el, ev_ms = timed(modes[0] if modes else None, 0)
     episodes = int(env.state("episode").sum()) - episodes0
