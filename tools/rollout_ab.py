@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--warm", type=int, default=50, help="single steps before the rollouts")
     ap.add_argument("--desync", action="store_true", help="spread the episode phases first")
     ap.add_argument("--reuse", action="store_true", help="write every rollout into the same output tensors")
+    ap.add_argument("--share", action="store_true", help="--reuse with ONE set of output tensors for all variants")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     import torch
@@ -47,8 +48,9 @@ def main():
     for rep in range(a.reps):
         for name, e in envs.items():
             e.timer_start()
-            o = e.rollout(acts, keep_obs=True, out=outs.get(name) if a.reuse else None)
-            outs[name] = o
+            key = "shared" if a.share else name
+            o = e.rollout(acts, keep_obs=True, out=outs.get(key) if (a.reuse or a.share) else None)
+            outs[key] = o
             print(f"rep {rep} {name:10s} {e.timer_stop() * 1e3 / a.k:7.2f} us/step", flush=True)
     for e in envs.values():
         e.close()
