@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--desync", action="store_true", help="spread the episode phases first")
     ap.add_argument("--reuse", action="store_true", help="write every rollout into the same output tensors")
     ap.add_argument("--share", action="store_true", help="--reuse with ONE set of output tensors for all variants")
+    ap.add_argument("--prealloc", action="store_true",
+                    help="--share with the output tensors allocated BEFORE anything else in the process")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     import torch
@@ -29,6 +31,14 @@ def main():
     data = [bench.synthetic_dataset(d, wl["T"], wl["n_static"]) for d in range(D)]
     dev = torch.device("cuda", 0)
     acts = torch.randint(0, 3, (a.k, N), dtype=torch.int32, device=dev)
+    pre = None
+    if a.prealloc:
+        a.share = True
+        W, F = wl["windows"] or 1, wl["n_static"] + 2
+        pre = {"reward": torch.empty((a.k, N), dtype=torch.float32, device=dev),
+               "terminated": torch.empty((a.k, N), dtype=torch.bool, device=dev),
+               "truncated": torch.empty((a.k, N), dtype=torch.bool, device=dev),
+               "obs": torch.empty((a.k, N, W, F), dtype=torch.float32, device=dev)}
     envs = {}
     for v in a.variants:
         name, _, kws = v.partition("=")
@@ -44,7 +54,7 @@ def main():
     out = torch.empty((a.k, N) + envs[a.variants[0].split("=")[0]].obs_shape, dtype=torch.float32, device=dev)
     print("obs buffer at 0x%x" % out.data_ptr())
     del out
-    outs = {}
+    outs = {"shared": pre} if pre is not None else {}
     for rep in range(a.reps):
         for name, e in envs.items():
             e.timer_start()
