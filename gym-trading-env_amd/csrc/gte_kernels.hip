@@ -242,6 +242,15 @@ __device__ inline void make_job(const Params& p, int e, const EnvRegs& s, bool f
 // ---------------------------------------------------------------------------
 // phase A
 
+// Prices a fused rollout carries from step to step (one lane = one env): a step trades at
+// close[idx] — the price the previous step valued the portfolio at — and values at close[idx+1],
+// which the previous step already asked for; the load that would head every step's dependency
+// chain is issued a step early instead.  Invalid (idx < 0) after anything but a plain step.
+struct PriceCarry {
+  double cur, next;  // close[idx], close[idx + 1] of dataset dsi
+  int32_t idx, dsi;
+};
+
 // compact: add the envs whose episode ended to the terminal list (off for the inner steps
 // of a fused rollout, which keeps per-step flags instead); pv_out: the valuation after the step.
 // carried: the env's registers live across calls (the fused rollout keeps them there for all K
@@ -251,7 +260,11 @@ template <int MODE>
 __device__ inline void phase_a(const Params& p, int e, bool active, int lane, ObsJob& job,
                                FinalJob* fin = nullptr, bool compact = true,
                                double* pv_out = nullptr, EnvRegs* carried = nullptr,
-                               const int32_t* action_in = nullptr) {
+                               const int32_t* action_in = nullptr, bool write_record = true,
+                               PriceCarry* pc = nullptr) {
+  // write_record = false (fused rollouts, with `carried`): the record is not written through on
+  // this step — the caller stores it once, after its last step (fields a reset or a limit-order
+  // fill changes are written where they change, whatever this flag says)
   if (fin) fin->flags = 0;
   job.src = nullptr; job.slot0 = 0; job.n_zero = 0; job.idx = 0; job.flags = 0;
 #pragma unroll
@@ -293,6 +306,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
         int32_t qi, qp, qd;
         pop_injection(p, e, s, qi, qp, qd);
         do_reset(p, e, qi, qp, qd, s, fresh);
+        if (pc) pc->idx = -1;
         p.reward[e] = 0.0f; p.reward64[e] = 0.0;
         p.terminated[e] = 0; p.truncated[e] = 0;
         stepped = false;
@@ -315,17 +329,24 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
       const DatasetDesc* dp = p.ds + s.dsi;
       const double* d_close = dp->close;
       const int32_t d_T = (int32_t)dp->T;
+      const bool carried_prices = pc && pc->idx == s.idx && pc->dsi == s.dsi;
       if (action >= 0) {  // :234 -> :213-215: trade only when the position VALUE differs
         const double position = p.positions[action];
         if (position != p.positions[s.pos]) {
-          trade_to_position(s.q, position, d_close[s.idx], p.fees);  // :204-209
+          trade_to_position(s.q, position, carried_prices ? pc->cur : d_close[s.idx], p.fees);  // :204-209
           s.pos = action;                                            // :210
         }
       }
       s.idx += 1;   // :235
       s.step += 1;  // :236
       if (p.lo_pos) fill_limit_orders(p, e, dp, s);  // :238
-      const double price = d_close[s.idx];  // :239
+      const double price = carried_prices ? pc->next : d_close[s.idx];  // :239
+      if (pc) {  // this step's valuation price is the next step's trade price; ask for the one after
+        pc->cur = price;
+        pc->idx = s.idx;
+        pc->dsi = s.dsi;
+        pc->next = (s.idx + 1 < d_T) ? d_close[s.idx + 1] : price;
+      }
       GTE_STAMP(3);  // descriptor, positions, trade, price at the new row arrived
       s.q.ia = pymax0(-s.q.asset) * p.rate;   // update_interest, portfolio.py:44-46
       s.q.ifi = pymax0(-s.q.fiat) * p.rate;
@@ -357,6 +378,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
         int32_t qi, qp, qd;
         pop_injection(p, e, s, qi, qp, qd);
         do_reset(p, e, qi, qp, qd, s, fresh);
+        if (pc) pc->idx = -1;
         if (fin && p.final_obs) {
           fin->src = term.src; fin->slot0 = term.slot0; fin->n_zero = term.n_zero; fin->flags = 1;
           // the reset's current row is about to overwrite one ring slot the terminal window
@@ -373,7 +395,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
     }
     GTE_STAMP(4);  // state machine done, outputs issued
     if (pv_out) *pv_out = s.pv;
-    store_state(p, e, s);
+    if (write_record) store_state(p, e, s);
     make_job(p, e, s, fresh, job);
     GTE_STAMP(5);  // record, ring and job stores done
   }
