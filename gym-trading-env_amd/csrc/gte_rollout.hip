@@ -523,6 +523,13 @@ hipError_t launch_rollout_resident(const Params& p, const RolloutArgs& r, int nt
   auto magic = [](uint32_t d) { return ((1ull << 40) + d - 1) / d; };
   const uint32_t FV = (uint32_t)p.Fobs / 4u;
   const uint64_t vlm = magic((uint32_t)(p.W - 1) * FV), fm = magic(FV);
+  if (smem > 64 * 1024) {  // the geometry search probed other sizes after this one: opt in again
+    hipError_t e;
+    if (nt == 2) e = hipFuncSetAttribute((const void*)gte_rollout_resident_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    else if (nt == 1) e = hipFuncSetAttribute((const void*)gte_rollout_resident_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    else e = hipFuncSetAttribute((const void*)gte_rollout_resident_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+  }
   if (nt == 2)
     hipLaunchKernelGGL((gte_rollout_resident_kernel<2>), dim3(blocks), dim3(256), smem, stream, p, r, vlm, fm);
   else if (nt == 1)
