@@ -13,9 +13,10 @@
 //     replaces the oldest one.  The dynamic columns are part of the LDS rows (patched when a
 //     row enters), so the emit is a pure copy.  A reset (or a dataset switch) re-anchors the
 //     env: its window is refilled from the table.  Wave 0 keeps every env's state in REGISTERS
-//     across the K steps (lane = env) and runs phase A one step ahead of the emit; the record,
-//     the dynamic ring in HBM and the per-step returns are still written through, so the
-//     env's state after the launch is exactly that of K gte_step calls.  LDS holds ~64 envs
+//     across the K steps (lane = env) and runs phase A one step ahead of the emit; the
+//     dynamic ring in HBM and the per-step returns are written through and the record is
+//     stored after the last step, so the env's state after the launch is exactly that of K
+//     gte_step calls.  LDS holds ~64 envs
 //     per CU at the headline shape (W-1 = 19 rows x 128 B = 2 432 B per env), so a batch
 //     runs as several rounds of workgroups, each going through all K steps.
 //   gte_rollout_kernel  (shapes whose window does not fit: fallback)  gathers every step's
@@ -464,8 +465,8 @@ __global__ __launch_bounds__(256, 4) void gte_rollout_resident_kernel(const Para
 // keeps rewards, flags and valuations; only the LAST step's observation exists afterwards, and
 // that step runs as an ordinary gte_step launch).  One lane per env, state in registers for all
 // n steps, next action loaded one step ahead, no LDS, no barrier: what is left per step is the
-// price loads and the fp64 state machine.  Record, dynamic ring and per-step returns are written
-// through exactly as gte_step would.
+// fp64 state machine (prices are carried from step to step, PriceCarry).  Dynamic ring and
+// per-step returns are written through exactly as gte_step would, the record once at the end.
 __global__ __launch_bounds__(256) void gte_rollout_state_kernel(const Params p0, const RolloutArgs r,
                                                                 const int n_steps, const int epw) {
   const int lane = threadIdx.x & 63;
