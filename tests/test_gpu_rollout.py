@@ -223,3 +223,37 @@ def test_rollout_random_shapes_equal_single_steps(seed):
             np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
     a.close()
     b.close()
+
+
+def test_long_rollouts_equal_single_steps():
+    """Hundreds of fused steps (many episodes per env, dataset switches, the LDS ring wrapping
+    dozens of times, prices and state carried in registers all the way): the state afterwards,
+    sampled rows on the way and the steps that follow equal single steps."""
+    import torch
+    data = [_data(300 + d, 900 + 13 * d, 14, sigma=1.5e-2)[:2] for d in range(3)]
+    N = 1500
+    kw = dict(positions=[-1, 0, 0.5, 1, 2], windows=10, trading_fees=1e-3, borrow_interest_rate=1e-4,
+              max_episode_duration=37, seed=5)
+    a, b = _twins(data, N, **kw)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1)
+    for K, keep in ((400, True), (700, False)):
+        acts = torch.randint(-1, 5, (K, N), dtype=torch.int32, device="cuda", generator=gen)
+        out = b.rollout(acts, keep_obs=keep, valuation=True)
+        for k in range(K):
+            obs, reward, term, trunc, _ = a.step(acts[k])
+            if k % 53 == 0 or k == K - 1:
+                assert torch.equal(out["reward"][k], reward), k
+                assert torch.equal(out["terminated"][k], term) and torch.equal(out["truncated"][k], trunc)
+                np.testing.assert_array_equal(out["valuation"][k].cpu().numpy(), a.state("portfolio_valuation"))
+                if keep:
+                    assert torch.equal(out["obs"][k], obs), k
+        if not keep:
+            assert torch.equal(out["obs"], obs)
+        _same_state(a, b, f"after K={K}")
+        del out
+    one = torch.randint(-1, 5, (N,), dtype=torch.int32, device="cuda", generator=gen)
+    for x, y in zip(a.step(one)[:4], b.step(one)[:4]):
+        assert torch.equal(x, y)
+    a.close()
+    b.close()
