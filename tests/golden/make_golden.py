@@ -506,7 +506,9 @@ def vector_example_fixture():
     assert len(infos) == n_envs * n_calls
     keys = list(infos[0])
     assert all(list(i) == keys for i in infos)
-    rec["info_keys"] = np.array(keys)
+    # the reference builds its info column list through a set() (environments.py:131): the ORDER
+    # of the data_* keys changes with the interpreter's hash seed, so the fixture stores them sorted
+    rec["info_keys"] = np.array(sorted(keys))
     for key in keys:  # run_trace goes env by env: infos[e * n_calls + k]
         col = [infos[e * n_calls + k][key] for k in range(n_calls) for e in range(n_envs)]
         if key == "date":
