@@ -638,11 +638,13 @@ def staging_fixture():
         os.path.join(HERE, "set_df.npz"),
         columns=np.array(cols), values=df[cols].to_numpy(np.float64),
         features_columns=np.array(env._features_columns),
-        info_columns=np.array(env._info_columns),
+        # (the reference builds this list through a set(): its order follows the hash seed; the
+        # fixture stores the columns sorted by name so that it regenerates bit-identically)
+        info_columns=np.array(sorted(env._info_columns)),
         nb_features=np.array(env._nb_features), nb_static_features=np.array(env._nb_static_features),
         obs_array=np.asarray(env._obs_array, np.float32),
         price_array=np.asarray(env._price_array, np.float64),
-        info_array=np.asarray(env._info_array, np.float64))
+        info_array=np.asarray(env._info_array, np.float64)[:, np.argsort(env._info_columns)])
     print("set_df.npz: features", env._features_columns, "info", env._info_columns)
 
 
