@@ -1126,6 +1126,11 @@ int gte_comm_init(gte_env* E, const uint8_t* id, int32_t rank, int32_t world) {
   HIPCHK(hipStreamCreateWithFlags(&E->comm_stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&E->comm_ready, hipEventDisableTiming));
   for (auto& ev : E->comm_done) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  if (E->gathered_returns) {  // a communicator of another size was here before
+    for (void*& q : E->allocs) if (q == (void*)E->gathered_returns) q = nullptr;
+    (void)hipFree(E->gathered_returns);
+    E->gathered_returns = nullptr;
+  }
   TRY(dev_alloc(E, &E->gathered_returns, (size_t)world * 6 * (size_t)E->p.N));
   HIPCHK(hipDeviceSynchronize());
   return GTE_OK;
@@ -1282,7 +1287,7 @@ void gte_destroy(gte_env* E) {
   (void)gte_comm_destroy(E);
   (void)hipStreamSynchronize(E->stream);
   if (E->own_stream) (void)hipStreamSynchronize(E->own_stream);
-  for (void* ptr : E->allocs) (void)hipFree(ptr);
+  for (void* ptr : E->allocs) if (ptr) (void)hipFree(ptr);
   for (auto& v : E->ds_allocs)
     for (void* ptr : v)
       if (ptr) (void)hipFree(ptr);
