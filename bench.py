@@ -323,7 +323,15 @@ def main():
                     help="block mode: blocks in rotation (a block's all-gather overlaps the steps "
                          "that fill the next one on RCCL's stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-python-loop", type=float, default=0.0, metavar="SECONDS",
+                    help="cpu_baseline calibration only, no GPU: time the interpreter-bound per-env loop "
+                         "(oracle/py_loop.py) on one core for SECONDS and print env-steps/s "
+                         "(tools/time_reference.py records it next to the reference's own timing)")
     args = ap.parse_args()
+    if args.cpu_python_loop > 0:  # part of the cpu_baseline leg: the only place that touches oracle/
+        from oracle.py_loop import time_loop
+        print(time_loop(seconds=args.cpu_python_loop)[0])
+        return
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a
     # version banner at communicator creation), so everything but that line goes to stderr.
     sys.stdout.flush()

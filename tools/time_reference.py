@@ -60,9 +60,11 @@ def main():
     # the build's own interpreter-bound loop (oracle/py_loop.py), timed HERE right after the
     # reference: bench.py times the same loop on the GPU box and uses the ratio to rescale
     # the reference's numbers to that box's cores
-    sys.path.insert(0, ROOT)
-    from oracle.py_loop import time_loop
-    rates = [time_loop(seconds=3.0)[0] for _ in range(3)]
+    # (through bench.py's cpu_baseline leg: nothing outside tests/, smoke() and that leg touches oracle/)
+    import subprocess
+    rates = [float(subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"),
+                                            "--cpu-python-loop", "3.0"]).decode().split()[-1])
+             for _ in range(3)]
     out["python_loop_c3_steps_per_s_1_process"] = float(np.median(rates))
     print("py_loop c3", rates, flush=True)
     with open(os.path.join(ROOT, "profiles", "reference_cpu_timing.json"), "w") as f:
