@@ -150,7 +150,14 @@ class BatchedTradingEnv(_VectorEnvBase):
         self.return_slots = int(return_slots)
         if self.return_slots < 1 or (self.return_slots > 1 and output != "torch"):
             raise ValueError("return_slots must be >= 1 (and > 1 only with output='torch')")
-        self.metadata = dict(self.metadata, autoreset_mode=autoreset or "disabled")
+        mode = autoreset or "disabled"
+        try:  # Gymnasium >= 1.0 wrappers read an AutoresetMode enum here (unpinned: not installed here)
+            from gymnasium.vector import AutoresetMode  # type: ignore
+            mode = {"next_step": AutoresetMode.NEXT_STEP, "same_step": AutoresetMode.SAME_STEP,
+                    "disabled": AutoresetMode.DISABLED}[mode]
+        except Exception:  # noqa: BLE001
+            pass
+        self.metadata = dict(self.metadata, autoreset_mode=mode)
         self.closed = False
         self._lib = _abi.load_library(library_path)  # raises if the HIP build is missing
         self._h = C.c_void_p()
