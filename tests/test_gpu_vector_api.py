@@ -211,10 +211,12 @@ def test_batched_history_access_patterns():
                                     max_episode_duration=15, log_steps=L, seed=4, output=output)
         env.reset()
         rng = np.random.default_rng(0)
-        for k in range(27):
-            env.step(rng.integers(0, 3, N).astype(np.int32))
-        h = env.batched_history()
         host = lambda x: x.numpy() if isinstance(x, DeviceArray) else np.asarray(x)
+        for k in range(27 + 61):  # first pass of the checks below at 28 rows, then past the ring's wrap
+            env.step(rng.integers(0, 3, N).astype(np.int32))
+            if k == 26:
+                break
+        h = env.batched_history()
         assert len(h) == 28 and (isinstance(h["idx", -1], DeviceArray) == (output == "torch"))
         for e in (0, 7, N - 1):
             he = env.history(e)  # the reference-style History of env e's current episode
@@ -237,6 +239,18 @@ def test_batched_history_access_patterns():
             h["no_such_column", -1]
         with pytest.raises(IndexError):
             h["idx", -29]
+        # past the wrap of the L-row device log: the window is the last L rows, oldest first
+        for k in range(61):
+            env.step(rng.integers(0, 3, N).astype(np.int32))
+        h = env.batched_history()
+        assert len(h) == L
+        for e in (3, N - 2):
+            he = env.history(e)
+            n = len(he)
+            for col in ("idx", "portfolio_valuation", "reward", "data_close"):
+                np.testing.assert_array_equal(host(h[col])[-n:, e], np.asarray(he[col], dtype=np.float64))
+                assert host(h[col, -1])[e] == he[col, -1] and host(h[col, 0])[e] == he[col, 0]
+            np.testing.assert_array_equal(host(h.episode_mask())[:, e], np.arange(L) >= L - n)
         env.close()
 
 
