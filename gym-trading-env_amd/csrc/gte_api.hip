@@ -31,10 +31,12 @@ int hot_blocks_per_cu_nt(size_t smem);
 struct RolloutArgs {  // mirrors gte_rollout.hip
   const int32_t* actions; int32_t K; float* obs; float* reward; double* reward64;
   uint8_t* terminated; uint8_t* truncated; double* valuation; int32_t epb;
+  int32_t n_groups; int32_t* group_counter;
 };
 size_t resident_lds_bytes(const Params& p, int epb);
 int resident_blocks_per_cu(const Params& p, int epb, int nt);
-hipError_t launch_rollout_resident(const Params& p, const RolloutArgs& r, int nt, hipStream_t stream);
+hipError_t launch_rollout_resident(const Params& p, const RolloutArgs& r, int nt, int blocks,
+                                   hipStream_t stream);
 hipError_t launch_rollout_state(const Params& p, const RolloutArgs& r, int n_steps, int epw,
                                 hipStream_t stream);
 hipError_t launch_rollout(const Params& p, const RolloutArgs& r, int nt, int blocks, int threads,
@@ -133,6 +135,8 @@ struct gte_env {
   gte::LogArrays log = {}; // device trajectory log (cfg.log_steps rows per env)
   int64_t log_rows = 0;
   int rollout_epw = 0;     // envs per wavefront of the fused rollout kernel (0 = not chosen yet)
+  int resident_slots[3] = {0, 0, 0};  // workgroups of that geometry the chip holds at once
+  int32_t* d_group_counter = nullptr; // the resident kernel's work queue (next group of envs)
   int resident_epb[3] = {0, 0, 0};  // envs per workgroup of the window-resident rollout kernel per
                                     // store policy (0 = not chosen yet, -1 = shape not covered)
   int hot_per_cu = 0;      // resident workgroups per CU the geometry was sized for (0 = n/a)
@@ -755,7 +759,7 @@ int gte_rollout(gte_env* E, const int32_t* actions, int32_t n_steps, const gte_r
     if (n_steps > 1) {
       TRY(count_steps(n_steps - 1));
       gte::RolloutArgs r = {actions, n_steps - 1, nullptr, b->reward, b->reward64, b->terminated,
-                            b->truncated, b->valuation, 0};
+                            b->truncated, b->valuation, 0, 0, nullptr};
       // identity order: with no window to gather, the L2-affinity order would only scatter the
       // per-env loads and stores (actions, rewards, flags) that are coalesced in env order
       Params ps = E->p;
@@ -792,16 +796,24 @@ int gte_rollout(gte_env* E, const int32_t* actions, int32_t n_steps, const gte_r
           if (per_cu <= 0) continue;
           const int64_t slots = (int64_t)per_cu * prop.multiProcessorCount;
           const int64_t wgs = ((int64_t)p.N + e - 1) / e;
-          const int64_t rounds = (wgs + slots - 1) / slots;
+          // the launch is a work queue over the groups: "rounds" is a real number, at least one
+          const double rounds = wgs > slots ? (double)wgs / (double)slots : 1.0;
           const double live = (double)(wgs < slots ? (wgs + prop.multiProcessorCount - 1) / prop.multiProcessorCount
                                                    : per_cu);  // workgroups sharing a CU
           const double us_bw = live * e * (double)p.W * p.Fobs * 4.0 / 22.0e3;  // ~5.6 TB/s over 256 CUs
-          const double cost = (double)rounds * (us_bw > 3.0 ? us_bw : 3.0);
+          // a workgroup's barriers and its state wave's latency are hidden by the OTHER workgroups
+          // of its CU: prefer four of them
+          const double alone = 1.0 + 0.05 * (double)(4 - (per_cu < 4 ? per_cu : 4));
+          const double cost = rounds * (us_bw > 3.0 ? us_bw : 3.0) * alone;
           if (getenv("GTE_DEBUG_GEOMETRY"))
             fprintf(stderr, "[gte] resident rollout, %2d envs/workgroup: LDS %6zu B, %d workgroups/CU, "
-                            "%lld workgroups, %lld round(s), cost %.1f\n", e, gte::resident_lds_bytes(p, e),
-                    per_cu, (long long)wgs, (long long)rounds, cost);
-          if (best == 0.0 || cost < best * 0.999) { best = cost; E->resident_epb[nt] = e; }
+                            "%lld groups, %.2f round(s), cost %.1f\n", e, gte::resident_lds_bytes(p, e),
+                    per_cu, (long long)wgs, rounds, cost);
+          if (best == 0.0 || cost < best * 0.999) {
+            best = cost;
+            E->resident_epb[nt] = e;
+            E->resident_slots[nt] = (int)slots;
+          }
         }
       }
     }
@@ -813,9 +825,17 @@ int gte_rollout(gte_env* E, const int32_t* actions, int32_t n_steps, const gte_r
       // per-step gather; here one row per env and step is read, and consecutive envs make each
       // workgroup's observation stores one contiguous run
       p.perm = nullptr;
+      if (!E->d_group_counter) {
+        TRY(dev_alloc(E, &E->d_group_counter, 4));
+        HIPCHK(hipDeviceSynchronize());  // (the zero-fill ran on the null stream)
+      }
+      HIPCHK(hipMemsetAsync(E->d_group_counter, 0, sizeof(int32_t), E->stream));
+      const int epb = E->resident_epb[nt];
+      const int n_groups = (p.N + epb - 1) / epb;
       gte::RolloutArgs r = {actions, n_steps, b->obs, b->reward, b->reward64, b->terminated,
-                            b->truncated, b->valuation, E->resident_epb[nt]};
-      const hipError_t le = gte::launch_rollout_resident(p, r, nt, E->stream);
+                            b->truncated, b->valuation, epb, n_groups, E->d_group_counter};
+      const int blocks = n_groups < E->resident_slots[nt] ? n_groups : E->resident_slots[nt];
+      const hipError_t le = gte::launch_rollout_resident(p, r, nt, blocks, E->stream);
       if (le != hipSuccess) return fail(GTE_ERR_HIP, "rollout launch: %s", hipGetErrorString(le));
     } else {
       if (E->rollout_epw == 0) {
@@ -840,7 +860,7 @@ int gte_rollout(gte_env* E, const int32_t* actions, int32_t n_steps, const gte_r
       p.epw = E->rollout_epw;
       const int r_blocks = (int)((((int64_t)p.N + p.epw - 1) / p.epw + 3) / 4);
       gte::RolloutArgs r = {actions, n_steps, b->obs, b->reward, b->reward64, b->terminated,
-                            b->truncated, b->valuation, 0};
+                            b->truncated, b->valuation, 0, 0, nullptr};
       const hipError_t le = gte::launch_rollout(p, r, E->cfg.nontemporal_obs, r_blocks, E->threads,
                                                 E->stream);
       if (le != hipSuccess) return fail(GTE_ERR_HIP, "rollout launch: %s", hipGetErrorString(le));

@@ -41,6 +41,8 @@ struct RolloutArgs {
   uint8_t* truncated;
   double* valuation;       // [K][N] or nullptr
   int32_t epb;             // resident kernel: envs per workgroup
+  int32_t n_groups;        // resident kernel: ceil(N / epb) groups of envs, handed out through ...
+  int32_t* group_counter;  // ... this device counter (zeroed before the launch)
 };
 
 // LDS: two sets of job records (wave 0 runs phase A one step ahead of the gather), two chunk
@@ -220,17 +222,16 @@ size_t resident_lds_bytes(const Params& p, int epb) {
 #define RES_NEW 2
 #define RES_OWNERS 192
 
+// One group of r.epb envs through all K steps (a workgroup takes group after group, below).
 template <int NT>
-__global__ __launch_bounds__(256, 4) void gte_rollout_resident_kernel(const Params p0, const RolloutArgs r,
-                                                                   const uint64_t vl_magic,
-                                                                   const uint64_t fv_magic) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char gte_smem[];
+__device__ __forceinline__ void resident_group(const Params& p0, const RolloutArgs& r,
+                                               const uint64_t vl_magic, const uint64_t fv_magic,
+                                               unsigned char* gte_smem, const int group) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wib = tid >> 6;
-  if (blockIdx.x == 0 && tid == 0) p0.term_count_next[0] = 0;
   const int EPB = r.epb;
-  const int wg_first = blockIdx.x * EPB;
+  const int wg_first = group * EPB;
   if (wg_first >= p0.N) return;
   const int n_wg = min(EPB, p0.N - wg_first);
   const ResLds L = carve_res(gte_smem, EPB);
@@ -501,6 +502,27 @@ hipError_t launch_rollout_state(const Params& p, const RolloutArgs& r, int n_ste
   return hipGetLastError();
 }
 
+// The launch is a WORK QUEUE over groups of r.epb envs: min(groups, resident slots) workgroups, each
+// taking the next group from a device counter until none is left.  Groups are independent (no
+// workgroup ever waits for another), so this only removes the quantisation of a plain grid, where
+// 6.1 "rounds" of workgroups cost 7: 100 003 envs are 6 251 groups on 1 024 slots.
+template <int NT>
+__global__ __launch_bounds__(256, 4) void gte_rollout_resident_kernel(const Params p0, const RolloutArgs r,
+                                                                   const uint64_t vl_magic,
+                                                                   const uint64_t fv_magic) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gte_smem[];
+  if (blockIdx.x == 0 && threadIdx.x == 0) p0.term_count_next[0] = 0;
+  int32_t* next_group = carve_res(gte_smem, r.epb).ctr + 2;
+  for (;;) {
+    if (threadIdx.x == 0) *next_group = atomicAdd(r.group_counter, 1);
+    GTE_LDS_BARRIER();
+    const int g = *next_group;
+    if (g >= r.n_groups) break;  // workgroup-uniform: the queue is empty
+    resident_group<NT>(p0, r, vl_magic, fv_magic, gte_smem, g);
+    GTE_LDS_BARRIER();  // every wave is done with this group's LDS image (and has read `g`)
+  }
+}
+
 int resident_blocks_per_cu(const Params& p, int epb, int nt) {
   int n = 0;
   const size_t smem = resident_lds_bytes(p, epb);
@@ -518,9 +540,9 @@ int resident_blocks_per_cu(const Params& p, int epb, int nt) {
   return n;
 }
 
-hipError_t launch_rollout_resident(const Params& p, const RolloutArgs& r, int nt, hipStream_t stream) {
+hipError_t launch_rollout_resident(const Params& p, const RolloutArgs& r, int nt, int blocks,
+                                   hipStream_t stream) {
   const size_t smem = resident_lds_bytes(p, r.epb);
-  const int blocks = (p.N + r.epb - 1) / r.epb;
   auto magic = [](uint32_t d) { return ((1ull << 40) + d - 1) / d; };
   const uint32_t FV = (uint32_t)p.Fobs / 4u;
   const uint64_t vlm = magic((uint32_t)(p.W - 1) * FV), fm = magic(FV);
