@@ -789,7 +789,9 @@ int gte_rollout(gte_env* E, const int32_t* actions, int32_t n_steps, const gte_r
       if (p.W >= 2 && !(E->cfg.kernel_variant & 256) &&
           hipGetDeviceProperties(&prop, E->cfg.device) == hipSuccess) {
         double best = 0.0;
+        const char* force = getenv("GTE_RESIDENT_EPB");  // tuning: envs per group, no search
         for (int e = 64; e >= 1; --e) {
+          if (force && atoi(force) != e) continue;
           if ((int64_t)e * FV > 2 * 192) continue;  // RES_NEW * RES_OWNERS newest-row vectors
           if (gte::resident_lds_bytes(p, e) > (size_t)160 * 1024) continue;
           const int per_cu = gte::resident_blocks_per_cu(p, e, nt);
@@ -803,7 +805,10 @@ int gte_rollout(gte_env* E, const int32_t* actions, int32_t n_steps, const gte_r
           const double us_bw = live * e * (double)p.W * p.Fobs * 4.0 / 22.0e3;  // ~5.6 TB/s over 256 CUs
           // a workgroup's barriers and its state wave's latency are hidden by the OTHER workgroups
           // of its CU: prefer four of them
-          const double alone = 1.0 + 0.05 * (double)(4 - (per_cu < 4 ? per_cu : 4));
+          // (measured at config 3, profiles/r02_resident_epb.log: 4 per CU 27.7 us per step, 3: 28.9,
+          // 2: 30.3, 1: 47.2)
+          static const double kAlone[5] = {1.7, 1.7, 1.10, 1.05, 1.0};
+          const double alone = kAlone[per_cu < 4 ? per_cu : 4];
           const double cost = rounds * (us_bw > 3.0 ? us_bw : 3.0) * alone;
           if (getenv("GTE_DEBUG_GEOMETRY"))
             fprintf(stderr, "[gte] resident rollout, %2d envs/workgroup: LDS %6zu B, %d workgroups/CU, "
