@@ -296,7 +296,10 @@ typedef struct gte_rollout_bufs {
  * observation unless bufs->obs was given (then that is row n_steps-1 of bufs->obs).  Shapes the
  * fused kernel does not cover (dyn_persist, final_obs, log_steps, scalar-vector layouts) run as
  * n_steps launches of the step kernel with the same results.  Per-step observation rows are
- * written with non-temporal stores under the automatic store policy (they are a stream). */
+ * written with non-temporal stores under the automatic store policy (they are a stream).
+ * Tuning only (results do not depend on it): the environment variable GTE_RESIDENT_EPB = 1..64
+ * fixes the envs per workgroup pass of the window-resident kernel instead of the geometry
+ * search in gte_api.hip (profiles/r02_resident_epb.log). */
 int gte_rollout(gte_env* env, const int32_t* actions, int32_t n_steps, const gte_rollout_bufs* bufs);
 
 /* Where the results of the last gte_step / gte_reset live (device pointers). */
