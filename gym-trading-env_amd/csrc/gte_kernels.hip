@@ -49,8 +49,18 @@ enum { MODE_STEP = 0, MODE_RESET = 1 };
         ((unsigned long long*)p.inj_ds)[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     }                                                                                         \
   } while (0)
+// slot k = where the calling wave runs instead of a time: HW_ID (SIMD_ID bits 5:4, CU_ID 11:8,
+// SH_ID 12, SE_ID 15:13) | XCC_ID << 32
+#define GTE_STAMP_HWID(k)                                                                     \
+  do {                                                                                        \
+    if (MODE == MODE_STEP && p.inj_ds && threadIdx.x == 0)                                    \
+      ((unsigned long long*)p.inj_ds)[blockIdx.x * 8 + (k)] =                                 \
+          (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                     \
+          ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);             \
+  } while (0)
 #else
 #define GTE_STAMP(k) do {} while (0)
+#define GTE_STAMP_HWID(k) do {} while (0)
 #endif
 
 // The part of an env's record a step works on, in registers.  The fields only a reset touches
@@ -772,6 +782,9 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
     if (wib == 1) prepare(0, min(p.epw, n_wg));
   }
   GTE_STAMP(1);  // env ids (perm) + rings arrived
+#ifdef GTE_STAMPS_HWID
+  GTE_STAMP_HWID(1);  // (diagnostic of the diagnostic: replaces stamp 1)
+#endif
 
   // ---- phase A
   if (!COOP || wib == 0) {  // wave-uniform
