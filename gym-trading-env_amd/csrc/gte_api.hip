@@ -389,7 +389,9 @@ int gte_create(const gte_config* cfg, gte_env** out) {
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
         double best = 0.0;
-        for (int e = 16; e >= 1; --e) {
+        int64_t one_round = 0;
+        int one_round_epw = 0, one_round_per_cu = 0;
+        for (int e = 64 / GTE_WAVES; e >= 1; --e) {
           if ((int64_t)e * vpe < 64) break;
           Params q = p;
           q.epw = e;  // registers AND the workgroup's LDS (which shrinks with e) bound residency
@@ -398,7 +400,7 @@ int gte_create(const gte_config* cfg, gte_env** out) {
                                                           : gte::hot_blocks_per_cu(smem);
           if (per_cu <= 0) break;
           const int64_t slots = (int64_t)per_cu * prop.multiProcessorCount;
-          const int64_t wgs = ((int64_t)p.N + 4 * e - 1) / (4 * e);
+          const int64_t wgs = ((int64_t)p.N + GTE_WAVES * e - 1) / (GTE_WAVES * e);
           const int64_t rounds = (wgs + slots - 1) / slots;
           const double cost = (double)rounds * (10.0 + 2.0 * e * (double)vpe / 160.0);
           if (getenv("GTE_DEBUG_GEOMETRY"))
@@ -406,21 +408,36 @@ int gte_create(const gte_config* cfg, gte_env** out) {
                             "%lld round(s), cost %.1f\n", e, smem, per_cu, (long long)wgs,
                     (long long)rounds, cost);
           if (best == 0.0 || cost < best) { best = cost; epw = e; E->hot_per_cu = per_cu; }
+          // All workgroups resident in one round with at least 16 waves on every CU: the launch
+          // then ends when the BUSIEST CU is done, so what counts is the envs on that CU
+          // (workgroups are dealt evenly: ceil(wgs / CUs) of them).  Config 3, us per step by
+          // envs on the busiest CU: 256 (16 per wave) 39.5, 260 (13) 40.4, 264 (11) 40.5,
+          // 280 (14) 40.7, 288 (12) 42.0, 300 (15) 42.0; config 5: 128 (8 per wave) 36.3, 64 per
+          // workgroup on 2 workgroups per CU 43.5 (profiles/r02_tune_epw.log, r02_waves_ab.log,
+          // r02_c5_sweep.log).  Ties go to the bigger workgroup (fewer phase-A waves).
+          const int64_t busiest = (wgs + prop.multiProcessorCount - 1) / prop.multiProcessorCount;
+          if (busiest <= per_cu && busiest * GTE_WAVES >= 16 &&
+              (one_round == 0 || busiest * e < one_round)) {
+            one_round = busiest * e;
+            one_round_epw = e;
+            one_round_per_cu = per_cu;
+          }
         }
+        if (one_round_epw) { epw = one_round_epw; E->hot_per_cu = one_round_per_cu; }
       }
     }
   }
   while (epw > 1 && (int64_t)epw * vpe > (1 << 20)) epw >>= 1;  // keeps the index math in range
   // the LDS-staged dynamic columns must fit comfortably: shrink the workgroup's envs
-  while (epw > 1 && (int64_t)epw * 4 * p.W * (p.nd ? p.nd : 1) * 4 > 32 * 1024) epw >>= 1;
+  while (epw > 1 && (int64_t)epw * GTE_WAVES * p.W * (p.nd ? p.nd : 1) * 4 > 32 * 1024) epw >>= 1;
   p.epw = epw;
   p.debug = cfg->debug_flags;
-  E->coop = (epw * 4 <= 64) && !(cfg->kernel_variant & 1);
+  E->coop = (epw * GTE_WAVES <= 64) && !(cfg->kernel_variant & 1);
   E->stage = (p.nd > 0 && gte::lds_bytes(p, 1) <= 48 * 1024 && !(cfg->kernel_variant & 2))
                  ? (p.persist ? 2 : 1) : 0;
   const int64_t waves = ((int64_t)p.N + epw - 1) / epw;
-  E->threads = 256;
-  E->blocks = (int)((waves + 3) / 4);
+  E->threads = 64 * GTE_WAVES;
+  E->blocks = (int)((waves + GTE_WAVES - 1) / GTE_WAVES);
   // L2-affinity order: only worth it when every XCD gets several workgroups and the
   // windows are big enough to be bandwidth-bound
   {
@@ -436,7 +453,7 @@ int gte_create(const gte_config* cfg, gte_env** out) {
       auto_period = auto_period < 8 ? 8 : (auto_period > 128 ? 128 : auto_period);
     }
     const int period = cfg->affinity_period == 0 ? auto_period : cfg->affinity_period;
-    const int EPB = epw * 4;
+    const int EPB = epw * GTE_WAVES;
     const int n_wg = (p.N + EPB - 1) / EPB;
     if (period > 0 && n_wg >= 64 && vpe * E->vec * 4 >= 512) {
       // slots in XCD-major order: workgroup b runs on XCD b % 8 (round-robin dispatch)

@@ -13,6 +13,13 @@
 
 #include "../../include/gte.h"
 
+// Wavefronts per workgroup of the step kernel (wave 0 runs phase A for the whole workgroup,
+// every wave gathers its own p.epw envs).  4 is the product; other values are for A/B builds
+// only (tools/waves_ab.sh): the rollout kernels assume 4.
+#ifndef GTE_WAVES
+#define GTE_WAVES 4
+#endif
+
 namespace gte {
 
 struct DatasetDesc {

@@ -33,7 +33,7 @@ hipError_t GTE_HOT_NAME(launch_step_hot)(const Params& p, int blocks, int thread
 int GTE_HOT_NAME(hot_blocks_per_cu)(size_t smem) {
   int n = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-          &n, gte_kernel<MODE_STEP, 4, GTE_HOT_NT, true, STAGE_RAW>, 256, smem) != hipSuccess)
+          &n, gte_kernel<MODE_STEP, 4, GTE_HOT_NT, true, STAGE_RAW>, 64 * GTE_WAVES, smem) != hipSuccess)
     return 0;
   return n;
 }

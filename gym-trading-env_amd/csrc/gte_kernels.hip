@@ -751,7 +751,7 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
   // the terminal counter has two slots used alternately, so no memset launch is
   // needed between steps: this launch clears the slot the NEXT launch will use
   if (MODE == MODE_STEP && blockIdx.x == 0 && threadIdx.x == 0) p.term_count_next[0] = 0;
-  const int EPB = p.epw * 4;  // envs per workgroup
+  const int EPB = p.epw * GTE_WAVES;  // envs per workgroup
   const int wg_first = blockIdx.x * EPB;
   if (wg_first >= p.N) return;  // whole workgroup exits together (before any barrier)
   const int n_wg = min(EPB, p.N - wg_first);
@@ -931,7 +931,7 @@ hipError_t launch_rewind_queue(EnvRec* rec, int n, hipStream_t stream) {
 static uint64_t magic40(uint32_t d) { return ((1ull << 40) + d - 1) / d; }
 
 size_t lds_bytes(const Params& p, int stage) {
-  const size_t EPB = (size_t)p.epw * 4;
+  const size_t EPB = (size_t)p.epw * GTE_WAVES;
   size_t b = EPB * (16 + 4 * GTE_MAX_DYN + 4) + (p.final_obs ? EPB * sizeof(FinalJob) : 0);
   if (stage) b += EPB * (size_t)p.W * (size_t)(p.nd ? p.nd : 1) * 4;
   return b;
