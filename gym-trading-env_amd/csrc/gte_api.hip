@@ -423,7 +423,24 @@ int gte_create(const gte_config* cfg, gte_env** out) {
             one_round_per_cu = per_cu;
           }
         }
-        if (one_round_epw) { epw = one_round_epw; E->hot_per_cu = one_round_per_cu; }
+        if (one_round_epw) {
+          epw = one_round_epw;
+          E->hot_per_cu = one_round_per_cu;
+        } else if (best != 0.0) {
+          // More workgroups than the chip holds at once (the observations stream to HBM): small
+          // workgroups win, the phase A of the ones that start later hides behind the copies of
+          // the ones already running and the tail is one small workgroup.  Config 3, us per step
+          // (profiles/r02_tune_epw_repeat.log; 3 passes each, +-3 % by buffer placement):
+          //   262 144 envs: 16 per wave 156.4, 12: 154.7, 8: 149.2, 6: 143.8-147.7, 4: 142.6, 3: 145.5, 2: 169.0
+          //   131 072 envs: 16: 86.7, 11: 83.3, 8: 80.1, 6: 79.0, 4: 78.2, 3: 79.8
+          //   100 003 envs: 16: 74.5, 9: 62.1, 6: 60.0, 4: 61.6, 3: 62.3
+          // -> about 640 vectors of copy work per wave (4 envs of 20x32), 960 below ~2 rounds of 6.
+          const int64_t target = (int64_t)p.N >= 120000 ? 640 : 960;
+          int e = (int)((target + vpe / 2) / vpe);
+          e = e < 1 ? 1 : (e > 64 / GTE_WAVES ? 64 / GTE_WAVES : e);
+          while (e < 64 / GTE_WAVES && (int64_t)e * vpe < 64) ++e;
+          epw = e;
+        }
       }
     }
   }
