@@ -159,6 +159,7 @@ static int dev_alloc(gte_env* E, T** out, size_t count, bool zero = true) {
   void* ptr = nullptr;
   size_t bytes = sizeof(T) * (count ? count : 1);
   HIPCHK(hipMalloc(&ptr, bytes));
+  if (getenv("GTE_DEBUG_ALLOC")) fprintf(stderr, "[gte] alloc %p %zu bytes\n", ptr, bytes);
   E->allocs.push_back(ptr);
   if (zero) HIPCHK(hipMemset(ptr, 0, bytes));
   *out = (T*)ptr;
@@ -537,6 +538,8 @@ int gte_upload_dataset(gte_env* E, int32_t d, const float* feat, const double* c
   for (int k = 0; k < 4; ++k) {
     if (!srcs[k]) continue;
     hipError_t e = hipMalloc(&dev[k], bytes[k]);
+    if (e == hipSuccess && getenv("GTE_DEBUG_ALLOC"))
+      fprintf(stderr, "[gte] dataset %d column %d at %p, %zu bytes\n", d, k, dev[k], bytes[k]);
     if (e == hipSuccess) e = hipMemcpy(dev[k], srcs[k], bytes[k], hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       undo();
