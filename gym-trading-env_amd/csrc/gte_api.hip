@@ -299,9 +299,9 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   chk(dev_alloc(E, &E->soa.asset, N)); chk(dev_alloc(E, &E->soa.fiat, N));
   chk(dev_alloc(E, &E->soa.ia, N)); chk(dev_alloc(E, &E->soa.ifi, N));
   chk(dev_alloc(E, &E->soa.pv, N)); chk(dev_alloc(E, &E->soa.realpos, N));
-  chk(dev_alloc(E, &E->owned.obs, N * p.W * p.Fobs));
+  // (the library's own observation buffers are allocated on first use, ensure_owned_obs: a caller
+  // that binds its own — the torch path — never pays for a second copy of [N, W, F_obs])
   if (cfg->final_obs) {
-    chk(dev_alloc(E, &E->owned.final_obs, N * p.W * p.Fobs));
     chk(dev_alloc(E, &p.final_rec, N));
     chk(dev_alloc(E, &E->fsoa.idx, N)); chk(dev_alloc(E, &E->fsoa.step, N));
     chk(dev_alloc(E, &E->fsoa.pos, N)); chk(dev_alloc(E, &E->fsoa.dsi, N));
@@ -348,8 +348,11 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   p.positions = d_pos;
   p.ds = E->d_ds;
   E->owned.obs_elems_per_env = (int64_t)p.W * p.Fobs;
-  p.final_obs = E->owned.final_obs;
-  p.obs = E->owned.obs; p.reward = E->owned.reward; p.reward64 = E->owned.reward64;
+  // the observation buffers come later (ensure_owned_obs / gte_bind_outputs); while the launch
+  // geometry is worked out below, a placeholder stands for "terminal observations are kept"
+  // (the LDS image has a FinalJob per env then, lds_bytes)
+  p.final_obs = cfg->final_obs ? (float*)(uintptr_t)16 : nullptr;
+  p.obs = nullptr; p.reward = E->owned.reward; p.reward64 = E->owned.reward64;
   p.terminated = E->owned.terminated; p.truncated = E->owned.truncated;
   E->term_base = E->owned.term_count; p.term_ids = E->owned.term_ids;
   E->h_ds.assign((size_t)p.D, DatasetDesc{nullptr, nullptr, nullptr, nullptr, 0});
@@ -499,6 +502,7 @@ int gte_create(const gte_config* cfg, gte_env** out) {
     gte_destroy(E);
     return fail(GTE_ERR_HIP, "hipDeviceSynchronize failed after allocation");
   }
+  p.final_obs = nullptr;  // (placeholder above)
   *out = E;
   return GTE_OK;
 }
@@ -629,10 +633,29 @@ static int stage(gte_env* E, void* dst, const void* src, size_t bytes) {
   return GTE_OK;
 }
 
+// The library's own observation buffers, on first need: nobody bound one (gte_bind_outputs) by
+// the first gte_reset / gte_get_outputs, or a binding was withdrawn.
+static int ensure_owned_obs(gte_env* E) {
+  Params& p = E->p;
+  const size_t elems = (size_t)p.N * (size_t)p.W * (size_t)p.Fobs;
+  bool fresh = false;
+  if (!p.obs) {
+    if (!E->owned.obs) { TRY(dev_alloc(E, &E->owned.obs, elems)); fresh = true; }
+    p.obs = E->owned.obs;
+  }
+  if (E->cfg.final_obs && !p.final_obs) {
+    if (!E->owned.final_obs) { TRY(dev_alloc(E, &E->owned.final_obs, elems)); fresh = true; }
+    p.final_obs = E->owned.final_obs;
+  }
+  if (fresh) HIPCHK(hipDeviceSynchronize());  // zero-filled on the null stream; E->stream is non-blocking
+  return GTE_OK;
+}
+
 int gte_reset(gte_env* E, const uint8_t* mask, const int32_t* inj_idx,
               const int32_t* inj_pos_index, const int32_t* inj_dataset) {
   if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
   HIPCHK(hipSetDevice(E->cfg.device));
+  TRY(ensure_owned_obs(E));
   TRY(finalize(E));
   TRY(check_injection(E, (size_t)E->p.N, inj_idx, inj_pos_index, inj_dataset));
   Params p = E->p;
@@ -1032,6 +1055,8 @@ int gte_set_log_reward(gte_env* E, const double* reward_device) {
 
 int gte_get_outputs(gte_env* E, gte_outputs* out) {
   if (!E || !out) return fail(GTE_ERR_INVALID, "NULL argument");
+  HIPCHK(hipSetDevice(E->cfg.device));
+  TRY(ensure_owned_obs(E));
   const Params& p = E->p;
   out->obs = p.obs; out->reward = p.reward; out->reward64 = p.reward64;
   out->terminated = p.terminated; out->truncated = p.truncated;
@@ -1048,8 +1073,9 @@ int gte_bind_outputs(gte_env* E, const gte_outputs* b) {
   HIPCHK(hipStreamSynchronize(E->stream));
   Params& p = E->p;
   if (b->obs && ((uintptr_t)b->obs & 15)) return fail(GTE_ERR_INVALID, "obs must be 16-byte aligned");
-  p.obs = b->obs ? b->obs : E->owned.obs;
-  if (E->cfg.final_obs) p.final_obs = b->final_obs ? b->final_obs : E->owned.final_obs;
+  p.obs = b->obs;  // NULL: back to the library's own buffers (allocated on first need)
+  if (E->cfg.final_obs) p.final_obs = b->final_obs;
+  if (E->was_reset) TRY(ensure_owned_obs(E));
   p.reward = b->reward ? b->reward : E->owned.reward;
   p.reward64 = b->reward64 ? b->reward64 : E->owned.reward64;
   p.terminated = b->terminated ? b->terminated : E->owned.terminated;

@@ -344,7 +344,10 @@ int gte_read_envs_view(gte_env* env, int32_t first, int32_t count, int32_t want_
 int gte_read_env(gte_env* env, int32_t env_index, gte_env_snapshot* out, float* obs);
 
 /* Use caller-owned device buffers for the outputs (e.g. torch tensors that are
- * then all-gathered over RCCL).  NULL members keep the library's buffer. */
+ * then all-gathered over RCCL).  NULL members keep the library's buffer.  The library's own
+ * observation buffers ([N, W, F_obs], and the final_obs one) are allocated on first need —
+ * the first gte_reset or gte_get_outputs that finds none bound — so a caller that binds its
+ * own before resetting never pays for a second copy. */
 int gte_bind_outputs(gte_env* env, const gte_outputs* bufs);
 /* Redirect ONLY the per-step returns (reward f32[N], terminated u8[N], truncated u8[N]) of
  * the steps enqueued AFTER this call; nothing is synchronised and nothing already

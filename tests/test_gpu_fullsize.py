@@ -201,3 +201,25 @@ def test_config5_full_T_invariants():
         n_ok += 1
     assert n_ok > len(picks) * 0.9
     env.close()
+
+
+def test_bound_outputs_do_not_pay_for_a_second_observation_buffer():
+    """The torch path binds its own tensors before the first reset: the library then never
+    allocates its own [N, W, F_obs] buffer (it did in round 1: 168 MB at the headline shape, 671 MB
+    at 262 144 envs).  Measured as the device memory the env takes."""
+    import torch
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    ds = _synthetic(77, 20_000, 30, sigma=1e-3)
+    n_envs = 65_536
+    obs_bytes = n_envs * 20 * 32 * 4
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    env = BatchedTradingEnv(ds, num_envs=n_envs, seed=5, max_episode_duration=50, **C3)
+    env.reset()
+    env.step(torch.zeros(n_envs, dtype=torch.int32, device="cuda"))
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    env.close()
+    taken = free0 - free1
+    assert obs_bytes < taken < 1.7 * obs_bytes, (taken / 1e6, obs_bytes / 1e6)
