@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--envs", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--affinity", type=int, default=0, help="L2-affinity period (0 default, -1 off)")
+    ap.add_argument("--lib", default=None, help="another build of libgte.so (A/B)")
     ap.add_argument("--desync", action="store_true",
                     help="spread the episode phases first (bench.desynchronise): ~N/500 envs end in "
                          "every step instead of all of them every 500 steps")
@@ -31,7 +32,7 @@ def main():
     data = [bench.synthetic_dataset(d, wl["T"], wl["n_static"]) for d in range(D)]
     dev = torch.device("cuda", 0)
     env = BatchedTradingEnv(data if D > 1 else data[0], num_envs=N, seed=1, output="torch",
-                            kernel_variant=a.variant, affinity_period=a.affinity,
+                            kernel_variant=a.variant, affinity_period=a.affinity, library_path=a.lib,
                             **bench.env_kwargs(wl))
     env.reset()
     W = wl["windows"] or 1
