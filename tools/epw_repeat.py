@@ -23,7 +23,9 @@ def main():
     for rep in range(3):
         for epw in [int(x) for x in os.environ.get("EPWS", "0 6 7 8 9 10 11 12 13 14 15 16").split()]:
             env = BatchedTradingEnv(data if D > 1 else data[0], num_envs=envs, seed=1, output="torch",
-                                    envs_per_wave=epw, **bench.env_kwargs(wl))
+                                    envs_per_wave=epw, kernel_variant=int(os.environ.get("VARIANT", "0")),
+                                    nontemporal_obs=int(os.environ.get("NT", "3")),
+                                    **bench.env_kwargs(wl))
             env.reset()
             bench.desynchronise(env, acts, wl["max_episode_duration"])
             for i in range(50):
