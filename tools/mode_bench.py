@@ -19,6 +19,7 @@ def main():
     base = bench.env_kwargs(wl)
     cases = [
         ("next_step (headline)", {}),
+        ("next_step, shared-TU build of the kernel", dict(kernel_variant=64)),
         ("same_step", dict(autoreset="same_step")),
         ("same_step + final_obs", dict(autoreset="same_step", final_obs=True)),
         ("next_step + log_steps=2", dict(log_steps=2)),
