@@ -480,12 +480,13 @@ def main():
         for i in range(args.steps):
             one_step(first_step + args.warmup + i)
         drain()  # every all-gather belongs to the timed region
-        ev_ms = env.timer_stop()
+        env.timer_mark()  # end event recorded behind the last launch; read after the wall clock
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+            torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
+        ev_ms = env.timer_stop()
         if world > 1:
             t = torch.tensor([el, ev_ms], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

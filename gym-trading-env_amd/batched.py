@@ -1027,6 +1027,10 @@ class BatchedTradingEnv(_VectorEnvBase):
     def timer_start(self):
         _abi.check(self._lib, self._lib.gte_timer_start(self._h))
 
+    def timer_mark(self):
+        """Record the end of the timed span now, without waiting (read it with `timer_stop`)."""
+        _abi.check(self._lib, self._lib.gte_timer_stop(self._h, None))
+
     def timer_stop(self) -> float:
         ms = C.c_float()
         _abi.check(self._lib, self._lib.gte_timer_stop(self._h, C.byref(ms)))

@@ -140,6 +140,7 @@ struct gte_env {
   int resident_epb[3] = {0, 0, 0};  // envs per workgroup of the window-resident rollout kernel per
                                     // store policy (0 = not chosen yet, -1 = shape not covered)
   int hot_per_cu = 0;      // resident workgroups per CU the geometry was sized for (0 = n/a)
+  bool timer_marked = false;  // gte_timer_stop(NULL) recorded the end event already
   bool store_auto = false; // the observation store policy was chosen here (cfg said 3)
   // multi-GPU return exchange (gte_comm.hip): one RCCL communicator per env
   void* comm = nullptr;
@@ -1323,8 +1324,14 @@ int gte_timer_start(gte_env* E) {
 }
 
 int gte_timer_stop(gte_env* E, float* elapsed_ms) {
-  if (!E || !elapsed_ms) return fail(GTE_ERR_INVALID, "NULL argument");
-  HIPCHK(hipEventRecord(E->ev1, E->stream));
+  if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
+  if (!elapsed_ms) {  // mark only: record the end now (asynchronous), read it with a later call
+    HIPCHK(hipEventRecord(E->ev1, E->stream));
+    E->timer_marked = true;
+    return GTE_OK;
+  }
+  if (!E->timer_marked) HIPCHK(hipEventRecord(E->ev1, E->stream));
+  E->timer_marked = false;
   HIPCHK(hipEventSynchronize(E->ev1));
   HIPCHK(hipEventElapsedTime(elapsed_ms, E->ev0, E->ev1));
   return GTE_OK;

@@ -401,7 +401,11 @@ int gte_synchronize(gte_env* env);
 
 /* HIP-event timing on the env's stream, for bench.py's roofline figure. */
 int gte_timer_start(gte_env* env);
-int gte_timer_stop(gte_env* env, float* elapsed_ms); /* synchronises */
+/* elapsed_ms != NULL: record the end event (unless already marked), wait for it, return the
+ * span.  elapsed_ms == NULL: only record the end event, asynchronously ("mark"); a later call
+ * with a pointer reads it — so that a wall-clock bracket around the same steps does not also
+ * pay for the event wait. */
+int gte_timer_stop(gte_env* env, float* elapsed_ms);
 
 /* Synchronous device -> host copies (the N=1 drop-in and the tests use them;
  * the batched path keeps everything on the device). */
