@@ -185,8 +185,10 @@ SYMBOLS = {
     "gte_read_log_portfolio": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 4
                                + [_P(C.c_int32)]),
     "gte_set_log_reward": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gte_apply_reward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "gte_get_final_state": (C.c_int, [C.c_void_p, _P(GteStateView)]),
     "gte_set_dynamic_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "gte_set_dynamic_columns": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_int32)]),
     "gte_read_log": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 8 + [_P(C.c_int32)]),
     "gte_get_outputs": (C.c_int, [C.c_void_p, _P(GteOutputs)]),
     "gte_get_state": (C.c_int, [C.c_void_p, _P(GteStateView)]),

@@ -641,34 +641,40 @@ class BatchedTradingEnv(_VectorEnvBase):
             r = to_tensor(self._reward_callable(h), dev, torch.float64)
             if r.shape != (N,):
                 raise ValueError(f"reward_function must return one value per env, got shape {tuple(r.shape)}")
-            reset_row = self._log_tensor("step")[newest] == 0
-            if same_step:
-                reset_row = reset_row & ~ended  # an ended env's reset row is overlaid by its terminal row
-            r = torch.where(self._t["terminated"] | reset_row, torch.zeros_like(r), r)
-            self._t["reward64"].copy_(r)
-            self._t["reward"].copy_(r.to(torch.float32))
-            self._set_log_reward(r)
+            # one kernel applies the reference's rules (0 where terminated, :265, and on reset rows,
+            # :196 — except, in same-step mode, under an ended env's terminal row) and writes the
+            # f64 / f32 returns and the newest log row (:267)
+            r = r.contiguous()
+            self._keep_reward = r
+            _abi.check(self._lib, self._lib.gte_apply_reward(self._h, C.c_void_p(r.data_ptr()),
+                                                             1 if same_step else 0))
         if self._dyn_callables:
-            vals = torch.zeros((N, self.cfg.n_dyn), dtype=torch.float32, device=dev)
-            mask = 0
+            cols = (C.c_void_p * self.cfg.n_dyn)()
+            is_f64 = (C.c_int32 * self.cfg.n_dyn)()
+            keep = []
             fresh = self.batched_history() if (same_step and bool(ended.any())) else None
             for i, fn in self._dyn_callables:
-                v = to_tensor(fn(h), dev, torch.float32)
+                v = to_tensor(fn(h), dev, None)
+                if v.dtype not in (torch.float32, torch.float64):
+                    v = v.to(torch.float64)
+                if v.shape != (N,):
+                    v = v.expand(N) if v.dim() == 0 else v.reshape(N)
                 if fresh is not None:
                     # the terminal observation shows the feature of the terminal row, the returned
                     # observation the one of the reset row (reset() evaluates it on a 1-row History)
                     col = self.datasets[0].n_static + i
                     fo = self._t["final_obs"]
                     if fo.dim() == 3:
-                        fo[ended, -1, col] = v[ended]
+                        fo[ended, -1, col] = v[ended].to(fo.dtype)
                     else:  # windows=None: the observation is one row
-                        fo[ended, col] = v[ended]
-                    v = torch.where(ended, to_tensor(fn(fresh), dev, torch.float32), v)
-                vals[:, i] = v
-                mask |= 1 << i
-            self._keep_dyn = vals
-            _abi.check(self._lib, self._lib.gte_set_dynamic_features(
-                self._h, C.c_void_p(vals.data_ptr()), mask))
+                        fo[ended, col] = v[ended].to(fo.dtype)
+                    v = torch.where(ended, to_tensor(fn(fresh), dev, v.dtype), v)
+                v = v.contiguous()
+                keep.append(v)
+                cols[i] = v.data_ptr()
+                is_f64[i] = 1 if v.dtype == torch.float64 else 0
+            self._keep_dyn = keep  # alive until the (stream-ordered) kernel has read them
+            _abi.check(self._lib, self._lib.gte_set_dynamic_columns(self._h, cols, is_f64))
 
     # -- trajectory log ------------------------------------------------------------------
     def add_metric(self, name, function):

@@ -39,6 +39,10 @@ hipError_t launch_rollout_resident(const Params& p, const RolloutArgs& r, int nt
                                    hipStream_t stream);
 hipError_t launch_rollout_state(const Params& p, const RolloutArgs& r, int n_steps, int epw,
                                 hipStream_t stream);
+hipError_t launch_set_dynamic_columns(const Params& p, const void* const* cols, const int32_t* is_f64,
+                                      hipStream_t stream);
+hipError_t launch_apply_reward(const Params& p, const double* reward, const int32_t* log_step_row,
+                               double* log_reward_row, int terminal_view, hipStream_t stream);
 hipError_t launch_rollout(const Params& p, const RolloutArgs& r, int nt, int blocks, int threads,
                           hipStream_t stream);
 int rollout_blocks_per_cu(const Params& p, int nt);
@@ -1054,6 +1058,17 @@ int gte_set_log_reward(gte_env* E, const double* reward_device) {
   return GTE_OK;
 }
 
+int gte_apply_reward(gte_env* E, const double* reward_device, int32_t terminal_view) {
+  if (!E || !reward_device) return fail(GTE_ERR_INVALID, "NULL argument");
+  if (E->cfg.log_steps <= 0) return fail(GTE_ERR_STATE, "created with log_steps = 0");
+  if (E->log_rows <= 0) return fail(GTE_ERR_STATE, "the log is empty");
+  HIPCHK(hipSetDevice(E->cfg.device));
+  const int64_t row = (E->log_rows - 1) % E->cfg.log_steps;
+  HIPCHK(gte::launch_apply_reward(E->p, reward_device, E->log.step + row * (int64_t)E->p.N,
+                                  E->log.reward + row * (int64_t)E->p.N, terminal_view ? 1 : 0, E->stream));
+  return GTE_OK;
+}
+
 int gte_get_outputs(gte_env* E, gte_outputs* out) {
   if (!E || !out) return fail(GTE_ERR_INVALID, "NULL argument");
   HIPCHK(hipSetDevice(E->cfg.device));
@@ -1174,6 +1189,15 @@ int gte_set_dynamic_features(gte_env* E, const float* values_device, uint32_t ma
     return fail(GTE_ERR_INVALID, "mask 0x%x names features beyond n_dyn = %d", mask, E->p.nd);
   HIPCHK(hipSetDevice(E->cfg.device));
   HIPCHK(gte::launch_set_dynamic(E->p, values_device, mask, E->stream));
+  return GTE_OK;
+}
+
+int gte_set_dynamic_columns(gte_env* E, const void* const* columns_device, const int32_t* is_f64) {
+  if (!E || !columns_device || !is_f64) return fail(GTE_ERR_INVALID, "NULL argument");
+  if (!E->was_reset) return fail(GTE_ERR_STATE, "gte_set_dynamic_columns before gte_reset");
+  if (E->p.nd <= 0) return fail(GTE_ERR_INVALID, "the env has no dynamic features");
+  HIPCHK(hipSetDevice(E->cfg.device));
+  HIPCHK(gte::launch_set_dynamic_columns(E->p, columns_device, is_f64, E->stream));
   return GTE_OK;
 }
 

@@ -60,6 +60,69 @@ hipError_t launch_set_dynamic(const Params& p, const float* values, uint32_t mas
   return hipGetLastError();
 }
 
+// The same from up to GTE_MAX_DYN separate device columns (f32 or f64 [N] each; NULL = leave the
+// feature alone): what a vectorised Python callable returns, without the caller packing and
+// converting them first (three small torch launches per feature).
+struct DynColumns {
+  const void* col[GTE_MAX_DYN];
+  int32_t is_f64[GTE_MAX_DYN];
+};
+
+__global__ void gte_set_dynamic_columns_kernel(const Params p, const DynColumns c) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.N) return;
+  const int32_t idx = p.rec[e].idx;
+  const int64_t slot = p.persist ? (int64_t)idx : (int64_t)(idx % p.W);
+  float* ring = p.ring + ((int64_t)e * p.depth + slot) * p.nd;
+  float* row = p.obs + ((int64_t)e * p.W + (p.W - 1)) * p.Fobs + p.Fs;
+  for (int i = 0; i < p.nd; ++i)
+    if (c.col[i]) {
+      // (float)double rounds to nearest even, like the reference's cast into its f32 _obs_array
+      const float v = c.is_f64[i] ? (float)((const double*)c.col[i])[e] : ((const float*)c.col[i])[e];
+      ring[i] = v;
+      row[i] = v;
+    }
+}
+
+hipError_t launch_set_dynamic_columns(const Params& p, const void* const* cols, const int32_t* is_f64,
+                                      hipStream_t stream) {
+  DynColumns c;
+  for (int i = 0; i < GTE_MAX_DYN; ++i) {
+    c.col[i] = i < p.nd ? cols[i] : nullptr;
+    c.is_f64[i] = i < p.nd ? is_f64[i] : 0;
+  }
+  hipLaunchKernelGGL(gte_set_dynamic_columns_kernel, dim3((p.N + 255) / 256), dim3(256), 0, stream, p, c);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// A user's reward_function evaluated outside the kernel, for the whole batch: the reference's
+// rules around it (environments.py:265-267: no reward when the step terminated; :196: rows a
+// reset wrote carry reward 0) and the three places the value lives — the f64 and f32 return
+// buffers and the newest row of the trajectory log (`historical_info["reward", -1] = reward`).
+// terminal_view (same-step auto-reset): an env that ended shows its TERMINAL row to the callable,
+// so the reset row underneath does not zero its reward.
+__global__ void gte_apply_reward_kernel(const Params p, const double* reward, const int32_t* log_step_row,
+                                        double* log_reward_row, int terminal_view) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.N) return;
+  const bool term = p.terminated[e] != 0;
+  const bool ended = term || p.truncated[e] != 0;
+  bool reset_row = log_step_row[e] == 0;
+  if (terminal_view) reset_row = reset_row && !ended;
+  const double r = (term || reset_row) ? 0.0 : reward[e];
+  p.reward64[e] = r;
+  p.reward[e] = (float)r;
+  log_reward_row[e] = r;
+}
+
+hipError_t launch_apply_reward(const Params& p, const double* reward, const int32_t* log_step_row,
+                               double* log_reward_row, int terminal_view, hipStream_t stream) {
+  hipLaunchKernelGGL(gte_apply_reward_kernel, dim3((p.N + 255) / 256), dim3(256), 0, stream, p, reward,
+                     log_step_row, log_reward_row, terminal_view);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // State, returns and observation of a range of envs, packed into (pinned, device-visible)
 // host memory: `count` gte_env_snapshot structs, then `count` observations.

@@ -240,6 +240,11 @@ int gte_add_limit_orders(gte_env* env, const int32_t* pos_index, const double* l
  * steps read it, and in the observation the last gte_step / gte_reset produced.  Stream-ordered;
  * call it after every step and reset. */
 int gte_set_dynamic_features(gte_env* env, const float* values_device, uint32_t mask);
+/* The same from n_dyn separate DEVICE columns, columns_device[i] = f32 or f64 [N] (is_f64[i]) or
+ * NULL to leave feature i alone: what a vectorised callable returns per feature, cast to f32 by
+ * the kernel the way the reference's assignment into its f32 _obs_array casts (:153-154).
+ * Both arrays are HOST arrays of n_dyn entries. */
+int gte_set_dynamic_columns(gte_env* env, const void* const* columns_device, const int32_t* is_f64);
 
 /* Device trajectory log (gte_config.log_steps = L): after every gte_reset / gte_step a small
  * kernel appends one row per env.  Row r of env e lives at index (r % L) * N + e of each
@@ -275,6 +280,13 @@ int gte_read_log_portfolio(gte_env* env, int32_t env_id, int32_t n, double* asse
  * reference does with a custom reward_function: `historical_info["reward", -1] = reward`
  * (environments.py:265-267).  Stream-ordered. */
 int gte_set_log_reward(gte_env* env, const double* reward_device);
+/* A custom reward_function's values for the whole batch (DEVICE f64 [N]), with the reference's
+ * rules around them applied by one kernel: reward 0 where the step terminated (environments.py
+ * :265: the function is not called when done) and on rows a reset wrote (:196), then written to
+ * the f32 and f64 return buffers and to the newest log row (:267).  terminal_view != 0 (same-step
+ * auto-reset): an env that ended was shown its terminal row, so its reset row does not zero the
+ * reward.  Needs log_steps > 0.  Stream-ordered. */
+int gte_apply_reward(gte_env* env, const double* reward_device, int32_t terminal_view);
 
 /* Per-step results of gte_rollout, all device pointers, all optional (NULL = not kept).
  * Row k holds what the k-th gte_step of the sequence would have produced. */

@@ -451,3 +451,58 @@ def test_same_step_finished_episode_history_and_custom_metrics():
     with pytest.raises(ValueError, match="did not end"):
         env.history(int(np.nonzero(~ended)[0][0]), finished=True)
     env.close(); twin.close()
+
+
+def test_apply_reward_and_dynamic_columns_entry_points():
+    """`gte_apply_reward` (the reference's rules around a custom reward, one kernel) against the
+    same rules written with torch ops, and `gte_set_dynamic_columns` (separate f32 / f64 columns)
+    against `gte_set_dynamic_features` (packed f32) on a twin env."""
+    import ctypes as C
+    import torch
+    from gym_trading_env_amd import _abi
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    rng = np.random.default_rng(3)
+    T, N = 600, 257
+    feat = rng.normal(size=(T, 3)).astype(np.float32)
+    close = 100 * np.exp(np.cumsum(rng.normal(0, 2e-2, T)))
+    kw = dict(num_envs=N, seed=9, positions=[-1, 0, 1], windows=4, trading_fees=1e-3,
+              borrow_interest_rate=1e-4, max_episode_duration=7, output="torch", log_steps=3)
+    for mode in ("next_step", "same_step"):
+        a = BatchedTradingEnv((feat, close), autoreset=mode, **kw)
+        b = BatchedTradingEnv((feat, close), autoreset=mode, **kw)
+        a.reset(); b.reset()
+        g = torch.Generator(device="cuda").manual_seed(1)
+        for k in range(25):
+            act = torch.randint(0, 3, (N,), dtype=torch.int32, device="cuda", generator=g)
+            a.step(act); b.step(act)
+            r = torch.randn(N, dtype=torch.float64, device="cuda", generator=g)
+            # reference rules with torch ops (what batched.py did before the entry point existed)
+            h = a.batched_history()
+            newest = (h._rows - 1) % h._L
+            term, trunc = a._t["terminated"].clone(), a._t["truncated"].clone()
+            reset_row = a._log_tensor("step")[newest] == 0
+            if mode == "same_step":
+                reset_row = reset_row & ~(term | trunc)
+            want = torch.where(term | reset_row, torch.zeros_like(r), r)
+            _abi.check(b._lib, b._lib.gte_apply_reward(b._h, C.c_void_p(r.data_ptr()),
+                                                       1 if mode == "same_step" else 0))
+            torch.cuda.synchronize()
+            assert torch.equal(b._t["reward64"], want)
+            assert torch.equal(b._t["reward"], want.to(torch.float32))
+            assert torch.equal(b._log_tensor("reward")[newest], want)
+            # dynamic columns: feature 0 from an f64 column, feature 1 from an f32 column
+            c0 = torch.randn(N, dtype=torch.float64, device="cuda", generator=g)
+            c1 = torch.randn(N, dtype=torch.float32, device="cuda", generator=g)
+            packed = torch.stack([c0.to(torch.float32), c1], dim=1).contiguous()
+            _abi.check(a._lib, a._lib.gte_set_dynamic_features(a._h, C.c_void_p(packed.data_ptr()), 3))
+            cols = (C.c_void_p * 2)(c0.data_ptr(), c1.data_ptr())
+            is64 = (C.c_int32 * 2)(1, 0)
+            _abi.check(b._lib, b._lib.gte_set_dynamic_columns(b._h, cols, is64))
+            torch.cuda.synchronize()
+            assert torch.equal(a._t["obs"], b._t["obs"])
+        # later windows read the stored values: the twins stay identical
+        for k in range(6):
+            act = torch.randint(0, 3, (N,), dtype=torch.int32, device="cuda", generator=g)
+            oa = a.step(act)[0]; ob = b.step(act)[0]
+            assert torch.equal(oa, ob)
+        a.close(); b.close()
