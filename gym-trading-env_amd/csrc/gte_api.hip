@@ -385,20 +385,30 @@ int gte_create(const gte_config* cfg, gte_env** out) {
     // (small windows are latency-bound: 16 envs/wave with cooperative phase A measured
     // 5.4 us vs 7.5 us at 64 envs/wave on config 2, profiles/r01_tune_c2.log)
     while (epw < 64 && (int64_t)epw * vpe < 64) epw <<= 1;
-    // Windowed shapes on the hot kernel: size the workgroups so that ALL of them are resident
-    // at once (or a whole number of such rounds).  A CU holds 5 workgroups of the hot kernel,
-    // 1280 in all; 65 536 envs as 1024 workgroups of 64 leave a fifth of the slots empty
-    // (42.9 us), as 1261 workgroups of 52 (13 per wave) they fill them (39.8 us), and as 1366
-    // workgroups of 48 the last 86 run alone afterwards (57.5 us) — profiles/r01_tune_epw.log.
-    // Cost model: rounds x (fixed part of a workgroup + its copy work).
+    // Windowed shapes on the hot kernel.  Two regimes, both measured:
+    //  * every workgroup resident at once, at least 16 waves on every CU: the launch ends when the
+    //    BUSIEST CU is done (workgroups are dealt evenly: ceil(wgs / CUs) per CU), so take the
+    //    envs-per-wave with the fewest envs on that CU; ties go to the bigger workgroup (fewer
+    //    phase-A waves).  Config 3, us per step by envs on the busiest CU: 256 (16 per wave) 39.5,
+    //    260 (13) 40.4, 264 (11) 40.5, 280 (14) 40.7, 288 (12) 42.0, 300 (15) 42.0; config 5:
+    //    128 (8 per wave, 4 workgroups per CU) 36.3, 16 per wave on 2 per CU 43.5
+    //    (profiles/r02_tune_epw.log, r02_waves_ab.log, r02_c5_sweep.log).
+    //  * more workgroups than the chip holds (the observations stream to HBM): small workgroups —
+    //    the phase A of those that start later hides behind the copies of those already running
+    //    and the tail is one small workgroup.  Config 3 (profiles/r02_tune_epw_repeat.log, 3 passes
+    //    each): 262 144 envs 16 per wave 156.4, 12: 154.7, 8: 149.2, 6: 143.8, 4: 142.6, 3: 145.5,
+    //    2: 169.0; 131 072 envs 16: 86.7, 11: 83.3, 8: 80.1, 6: 79.0, 4: 78.2, 3: 79.8; 100 003 envs
+    //    16: 74.5, 9: 62.1, 6: 60.0, 4: 61.6 -> about 640 vectors of copy work per wave (4 envs
+    //    of 20x32), 960 below 120 000 envs.
     const bool hot_shape = E->vec == 4 && vpe >= 64 && p.nd > 0 && !p.persist && !cfg->final_obs &&
                            (E->cfg.nontemporal_obs == 1 || E->cfg.nontemporal_obs == 2) &&
                            !(cfg->kernel_variant & (1 | 2));
     if (hot_shape) {
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
-        double best = 0.0;
-        int64_t one_round = 0;
+        const int64_t n_cu = prop.multiProcessorCount;
+        int some_per_cu = 0;  // (residency of any candidate: the occupancy queries work)
+        int64_t fewest = 0;
         int one_round_epw = 0, one_round_per_cu = 0;
         for (int e = 64 / GTE_WAVES; e >= 1; --e) {
           if ((int64_t)e * vpe < 64) break;
@@ -408,26 +418,14 @@ int gte_create(const gte_config* cfg, gte_env** out) {
           const int per_cu = E->cfg.nontemporal_obs == 1 ? gte::hot_blocks_per_cu_nt(smem)
                                                           : gte::hot_blocks_per_cu(smem);
           if (per_cu <= 0) break;
-          const int64_t slots = (int64_t)per_cu * prop.multiProcessorCount;
+          if (e <= 8 || !some_per_cu) some_per_cu = per_cu;
           const int64_t wgs = ((int64_t)p.N + GTE_WAVES * e - 1) / (GTE_WAVES * e);
-          const int64_t rounds = (wgs + slots - 1) / slots;
-          const double cost = (double)rounds * (10.0 + 2.0 * e * (double)vpe / 160.0);
+          const int64_t busiest = (wgs + n_cu - 1) / n_cu;  // workgroups on the busiest CU
           if (getenv("GTE_DEBUG_GEOMETRY"))
-            fprintf(stderr, "[gte] envs/wave %2d: LDS %5zu B, %d workgroups/CU, %lld workgroups, "
-                            "%lld round(s), cost %.1f\n", e, smem, per_cu, (long long)wgs,
-                    (long long)rounds, cost);
-          if (best == 0.0 || cost < best) { best = cost; epw = e; E->hot_per_cu = per_cu; }
-          // All workgroups resident in one round with at least 16 waves on every CU: the launch
-          // then ends when the BUSIEST CU is done, so what counts is the envs on that CU
-          // (workgroups are dealt evenly: ceil(wgs / CUs) of them).  Config 3, us per step by
-          // envs on the busiest CU: 256 (16 per wave) 39.5, 260 (13) 40.4, 264 (11) 40.5,
-          // 280 (14) 40.7, 288 (12) 42.0, 300 (15) 42.0; config 5: 128 (8 per wave) 36.3, 64 per
-          // workgroup on 2 workgroups per CU 43.5 (profiles/r02_tune_epw.log, r02_waves_ab.log,
-          // r02_c5_sweep.log).  Ties go to the bigger workgroup (fewer phase-A waves).
-          const int64_t busiest = (wgs + prop.multiProcessorCount - 1) / prop.multiProcessorCount;
-          if (busiest <= per_cu && busiest * GTE_WAVES >= 16 &&
-              (one_round == 0 || busiest * e < one_round)) {
-            one_round = busiest * e;
+            fprintf(stderr, "[gte] envs/wave %2d: LDS %5zu B, %d workgroups/CU resident, %lld workgroups, "
+                            "%lld on the busiest CU\n", e, smem, per_cu, (long long)wgs, (long long)busiest);
+          if (busiest <= per_cu && busiest * GTE_WAVES >= 16 && (fewest == 0 || busiest * e < fewest)) {
+            fewest = busiest * e;
             one_round_epw = e;
             one_round_per_cu = per_cu;
           }
@@ -435,15 +433,8 @@ int gte_create(const gte_config* cfg, gte_env** out) {
         if (one_round_epw) {
           epw = one_round_epw;
           E->hot_per_cu = one_round_per_cu;
-        } else if (best != 0.0) {
-          // More workgroups than the chip holds at once (the observations stream to HBM): small
-          // workgroups win, the phase A of the ones that start later hides behind the copies of
-          // the ones already running and the tail is one small workgroup.  Config 3, us per step
-          // (profiles/r02_tune_epw_repeat.log; 3 passes each, +-3 % by buffer placement):
-          //   262 144 envs: 16 per wave 156.4, 12: 154.7, 8: 149.2, 6: 143.8-147.7, 4: 142.6, 3: 145.5, 2: 169.0
-          //   131 072 envs: 16: 86.7, 11: 83.3, 8: 80.1, 6: 79.0, 4: 78.2, 3: 79.8
-          //   100 003 envs: 16: 74.5, 9: 62.1, 6: 60.0, 4: 61.6, 3: 62.3
-          // -> about 640 vectors of copy work per wave (4 envs of 20x32), 960 below ~2 rounds of 6.
+        } else if (some_per_cu) {
+          E->hot_per_cu = some_per_cu;
           const int64_t target = (int64_t)p.N >= 120000 ? 640 : 960;
           int e = (int)((target + vpe / 2) / vpe);
           e = e < 1 ? 1 : (e > 64 / GTE_WAVES ? 64 / GTE_WAVES : e);
