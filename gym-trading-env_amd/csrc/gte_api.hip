@@ -52,12 +52,6 @@ struct StateSoA {
 };
 hipError_t launch_extract_state(const EnvRec* rec, int n, const StateSoA& o, hipStream_t stream);
 hipError_t launch_rewind_queue(EnvRec* rec, int n, hipStream_t stream);
-struct LogArrays {
-  int32_t *idx, *step, *pos, *dsi;
-  double *pv, *realpos, *reward;
-  uint8_t* flags;
-  double *asset, *fiat, *ia, *ifi;
-};
 hipError_t launch_log(const EnvRec* rec, const double* reward64, const uint8_t* term,
                       const uint8_t* trunc, int n, int64_t row_base, const LogArrays& o,
                       hipStream_t stream);
@@ -737,16 +731,28 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
   E->term_slot ^= 1;
   p.term_count = E->term_base + E->term_slot;
   p.term_count_next = E->term_base + (E->term_slot ^ 1);
-  if (E->vec == 4 && E->cfg.nontemporal_obs == 2 && E->coop && E->stage == 1 &&
-           !(E->cfg.kernel_variant & 64))
+  // With a trajectory log the step kernel writes the row itself (shared-TU instantiation, same
+  // speed as the isolated ones at today's geometry, profiles/r02_mode_bench.log) where that beats
+  // a second launch (profiles/r02_log_ab.log, config-3 shape, us per step kernel row / separate):
+  // 8 192 envs 11.2 / 14.3, 16 384: 16.0 / 19.0, 32 768: 27.6 / 26.8, 65 536: 49.1 / 44.7 with the
+  // L2-affinity order (the row's 12 stores per lane are scattered then); 53.5 / 57.4 without it.
+  // kernel_variant bit 1024 always keeps the separate gte_log_kernel launch, 2048 never does.
+  const bool fused_log = E->cfg.log_steps > 0 && !(E->cfg.kernel_variant & 1024) &&
+                         ((E->cfg.kernel_variant & 2048) || !p.perm || p.N <= 16384);
+  if (fused_log) {
+    p.log = E->log;
+    p.log_row_base = (E->log_rows % E->cfg.log_steps) * (int64_t)p.N;
+  }
+  const bool hot = E->vec == 4 && E->coop && E->stage == 1 && !(E->cfg.kernel_variant & 64) && !fused_log;
+  if (hot && E->cfg.nontemporal_obs == 2)
     HIPCHK(gte::launch_step_hot(p, E->blocks, E->threads, gte::lds_bytes(p, E->stage), E->stream));
-  else if (E->vec == 4 && E->cfg.nontemporal_obs == 1 && E->coop && E->stage == 1 &&
-           !(E->cfg.kernel_variant & 64))
+  else if (hot && E->cfg.nontemporal_obs == 1)
     HIPCHK(gte::launch_step_hot_nt(p, E->blocks, E->threads, gte::lds_bytes(p, E->stage), E->stream));
   else
     HIPCHK(gte::launch_step(p, E->vec, E->cfg.nontemporal_obs, E->coop, E->stage, E->blocks,
                             E->threads, E->stream));
-  TRY(append_log(E));
+  if (fused_log) E->log_rows += 1;
+  else TRY(append_log(E));
   return GTE_OK;
 }
 

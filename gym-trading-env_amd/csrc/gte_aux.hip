@@ -6,15 +6,8 @@
 namespace gte {
 
 // ---------------------------------------------------------------------------
-// Trajectory log (optional, gte_config.log_steps): one row per env after every reset /
-// step — what History.add records (reference environments.py:253-264).
-struct LogArrays {
-  int32_t *idx, *step, *pos, *dsi;
-  double *pv, *realpos, *reward;
-  uint8_t* flags;
-  double *asset, *fiat, *ia, *ifi;  // Portfolio state: get_portfolio_distribution (portfolio.py:49-57)
-};
-
+// Trajectory log (LogArrays, gte_device.h): the row of a reset, of a step of the kernels that do
+// not write it themselves (the isolated hot instantiations, the unfused rollout loop).
 __global__ void gte_log_kernel(const EnvRec* rec, const double* reward64, const uint8_t* term,
                                const uint8_t* trunc, int n, int64_t row_base, LogArrays o) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;

@@ -42,6 +42,15 @@ struct alignas(128) EnvRec {
 };
 static_assert(sizeof(EnvRec) == 128, "EnvRec must be one 128-byte line");
 
+// Trajectory log (optional, gte_config.log_steps): [L, N] arrays, one row per env after every
+// reset / step — what History.add records (reference environments.py:253-264).
+struct LogArrays {
+  int32_t *idx, *step, *pos, *dsi;
+  double *pv, *realpos, *reward;
+  uint8_t* flags;
+  double *asset, *fiat, *ia, *ifi;  // Portfolio state: get_portfolio_distribution (portfolio.py:49-57)
+};
+
 // Everything a launch needs; passed by value as the kernel argument.
 struct Params {
   // --- configuration (from gte_config)
@@ -84,6 +93,10 @@ struct Params {
   const int32_t* perm; // processing slot -> env id (L2-affinity order), or null = identity
   int32_t epw;         // environments per wavefront
   int32_t debug;       // gte_config.debug_flags (timing ablations)
+  // --- trajectory row written by THIS launch's phase A (a gte_step with log_steps > 0; the
+  // shared-TU step kernel only).  log.idx == null: none (the host appends it with gte_log_kernel)
+  LogArrays log;
+  int64_t log_row_base;  // index of env 0 in the row being written: (row % L) * N
 };
 
 // ---------------------------------------------------------------------------

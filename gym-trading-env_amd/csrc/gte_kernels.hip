@@ -256,6 +256,13 @@ __device__ inline void make_job(const Params& p, int e, const EnvRegs& s, bool f
 // close[idx] — the price the previous step valued the portfolio at — and values at close[idx+1],
 // which the previous step already asked for; the load that would head every step's dependency
 // chain is issued a step early instead.  Invalid (idx < 0) after anything but a plain step.
+// What a step returned for one env, for a caller that also writes the trajectory row.
+struct StepOut {
+  double reward, pv, realpos, asset, fiat, ia, ifi;  // reward of the step; the rest: state after it
+  int32_t idx, step, pos, dsi;
+  int32_t flags;  // bit0 terminated, bit1 truncated
+};
+
 struct PriceCarry {
   double cur, next;  // close[idx], close[idx + 1] of dataset dsi
   int32_t idx, dsi;
@@ -271,7 +278,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
                                FinalJob* fin = nullptr, bool compact = true,
                                double* pv_out = nullptr, EnvRegs* carried = nullptr,
                                const int32_t* action_in = nullptr, bool write_record = true,
-                               PriceCarry* pc = nullptr) {
+                               PriceCarry* pc = nullptr, StepOut* so = nullptr) {
   // write_record = false (fused rollouts, with `carried`): the record is not written through on
   // this step — the caller stores it once, after its last step (fields a reset or a limit-order
   // fill changes are written where they change, whatever this flag says)
@@ -319,6 +326,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
         if (pc) pc->idx = -1;
         p.reward[e] = 0.0f; p.reward64[e] = 0.0;
         p.terminated[e] = 0; p.truncated[e] = 0;
+        if (so) { so->reward = 0.0; so->flags = 0; }
         stepped = false;
       } else if (s.idx >= (int32_t)p.ds[s.dsi].T - 1) {
         // no auto-reset and no row left: the reference raises IndexError (:239);
@@ -329,6 +337,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
         // being on the last row is the truncation rule itself (:248)
         p.terminated[e] = (s.pv / p.V0) <= 0.7 ? 1 : 0;
         p.truncated[e] = 1;
+        if (so) { so->reward = 0.0; so->flags = ((s.pv / p.V0) <= 0.7 ? 1 : 0) | 2; }
         stepped = false;
         ended = true;  // so it stays in the terminal list
       }
@@ -372,6 +381,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
       p.reward[e] = (float)rew;
       p.terminated[e] = done ? 1 : 0;
       p.truncated[e] = trunc ? 1 : 0;
+      if (so) { so->reward = rew; so->flags = (done ? 1 : 0) | (trunc ? 2 : 0); }
       ended = done || trunc;
       if (ended) s.needs_reset = 1;
       if (ended && p.autoreset == GTE_AUTORESET_SAME_STEP) {
@@ -406,6 +416,11 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
     GTE_STAMP(4);  // state machine done, outputs issued
     if (pv_out) *pv_out = s.pv;
     if (write_record) store_state(p, e, s);
+    if (so) {
+      so->idx = s.idx; so->step = s.step; so->pos = s.pos; so->dsi = s.dsi;
+      so->pv = s.pv; so->realpos = s.realpos;
+      so->asset = s.q.asset; so->fiat = s.q.fiat; so->ia = s.q.ia; so->ifi = s.q.ifi;
+    }
     make_job(p, e, s, fresh, job);
     GTE_STAMP(5);  // record, ring and job stores done
   }
@@ -799,6 +814,23 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
     const int e = active ? (p.perm ? p.perm[wg_first + s] : wg_first + s) : 0;
     ObsJob job;
     FinalJob fin;
+#ifndef GTE_HOT_ONLY  // (the isolated hot instantiations never write the trajectory row)
+    if (MODE == MODE_STEP && p.log.idx) {
+      // gte_step with log_steps: the lane that stepped the env also writes its trajectory row —
+      // what History.add records (environments.py:253-264) — from its registers, instead of a
+      // second launch reading everything back (4.5 us per step)
+      StepOut so = {};
+      phase_a<MODE>(p, e, active, lane, job, p.final_obs ? &fin : nullptr, true, nullptr, nullptr, nullptr,
+                    true, nullptr, &so);
+      if (active) {
+        const int64_t k = p.log_row_base + e;
+        p.log.idx[k] = so.idx; p.log.step[k] = so.step; p.log.pos[k] = so.pos; p.log.dsi[k] = so.dsi;
+        p.log.pv[k] = so.pv; p.log.realpos[k] = so.realpos; p.log.reward[k] = so.reward;
+        p.log.asset[k] = so.asset; p.log.fiat[k] = so.fiat; p.log.ia[k] = so.ia; p.log.ifi[k] = so.ifi;
+        p.log.flags[k] = (uint8_t)so.flags;
+      }
+    } else
+#endif
     phase_a<MODE>(p, e, active, lane, job, p.final_obs ? &fin : nullptr);
     if (owns) publish_job(L, s, job);  // slots past the last env get flags = 0
     if (owns && p.final_obs) L.fin[s] = fin;

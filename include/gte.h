@@ -124,7 +124,10 @@ typedef struct gte_config {
                                128 = gte_rollout runs as one launch per step even
                                where the fused kernels apply, 256 = gte_rollout uses
                                the gather-per-step fused kernel instead of the
-                               window-resident one                                 */
+                               window-resident one, 1024 = gte_step always appends
+                               the trajectory row with a separate small launch, 2048 =
+                               always inside the step kernel (default: whichever
+                               measured faster for the batch size)                  */
   int32_t debug_flags;      /* timing ablations only (results become wrong):
                                1 = skip the observation gather, 2 = skip the
                                dynamic-column patch, 8 = skip the window loads

@@ -506,3 +506,35 @@ def test_apply_reward_and_dynamic_columns_entry_points():
             oa = a.step(act)[0]; ob = b.step(act)[0]
             assert torch.equal(oa, ob)
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("mode", ["next_step", "same_step", "disabled"])
+def test_trajectory_row_written_by_the_step_kernel_equals_the_separate_launch(mode):
+    """With `log_steps` the step kernel's phase A writes the trajectory row itself; kernel_variant
+    bit 1024 keeps round 1's separate log launch.  Every column of every row must be identical,
+    resets and frozen envs included."""
+    import torch
+    from gym_trading_env_amd import _abi
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    rng = np.random.default_rng(11)
+    T, N, L = 300, 193, 5
+    feat = rng.normal(size=(T, 6)).astype(np.float32)
+    close = 100 * np.exp(np.cumsum(rng.normal(0, 3e-2, T)))
+    kw = dict(num_envs=N, seed=4, positions=[-1, 0, 0.5, 2], windows=3, trading_fees=1e-3,
+              borrow_interest_rate=1e-3, max_episode_duration=9, output="torch", log_steps=L,
+              autoreset=mode, final_obs=(mode == "same_step"))
+    a = BatchedTradingEnv((feat, close), kernel_variant=2048, **kw)   # row written in the kernel
+    b = BatchedTradingEnv((feat, close), kernel_variant=1024, **kw)   # separate launch
+    a.reset(); b.reset()
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for k in range(40):
+        act = torch.randint(-1, 4, (N,), dtype=torch.int32, device="cuda", generator=g)
+        ra = a.step(act); rb = b.step(act)
+        for x, y in zip(ra[:4], rb[:4]):
+            assert torch.equal(x, y)
+        for name in _abi.LOG_DTYPES:
+            assert torch.equal(a._log_tensor(name), b._log_tensor(name)), (mode, k, name)
+        if mode == "disabled" and k % 7 == 6:
+            m = (a._t["terminated"] | a._t["truncated"]).to(torch.uint8).cpu().numpy()
+            a.reset(mask=m); b.reset(mask=m)
+    a.close(); b.close()
