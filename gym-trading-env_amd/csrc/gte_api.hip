@@ -1283,6 +1283,7 @@ int gte_allgather_returns(gte_env* E, void* dst_device, int32_t mode, const void
 int gte_allgather_obs(gte_env* E, float* dst_device, int32_t mode) {
   if (!E || !dst_device) return fail(GTE_ERR_INVALID, "NULL argument");
   const Params& p = E->p;
+  if (!p.obs) return fail(GTE_ERR_STATE, "gte_allgather_obs before gte_reset (no observation exists yet)");
   return gte_allgather(E, p.obs, dst_device, sizeof(float) * (size_t)p.N * p.W * p.Fobs, mode);
 }
 
@@ -1364,6 +1365,7 @@ int gte_read_obs(gte_env* E, int32_t first_env, int32_t n, float* host_dst) {
   if (first_env < 0 || n < 0 || (int64_t)first_env + n > p.N)
     return fail(GTE_ERR_INVALID, "env range [%d, %d) out of [0, %d)", first_env, first_env + n, p.N);
   const size_t per = (size_t)p.W * p.Fobs;
+  if (!p.obs) return fail(GTE_ERR_STATE, "gte_read_obs before gte_reset (no observation exists yet)");
   HIPCHK(hipStreamSynchronize(E->stream));
   HIPCHK(hipMemcpy(host_dst, p.obs + per * first_env, sizeof(float) * per * n, hipMemcpyDeviceToHost));
   return GTE_OK;
