@@ -42,6 +42,12 @@ probe finds faster on the node (`auto`, the default); `block` moves a --gather-e
 block at a time on RCCL's stream while the following steps run and is reported
 beside it (config.other_gather_modes);
 --gather-obs adds the observation all-gather (xGMI-bound).  Weak scaling: 65 536 envs/GPU.
+
+`python3 bench.py --gpus N` from a bare shell starts its own N ranks (fresh child processes under
+torch.distributed.run, before this process touches the GPU) and relays rank 0's line; under an
+external torchrun it runs as one rank.  Workloads: c3 (headline), c2, c4 (BASELINE config 4:
+32 768 envs per GPU, returns AND observations all-gathered; also reported without the observation
+gather), c5 (128 symbols per GPU, partitioned by rank).
 """
 from __future__ import annotations
 
@@ -71,6 +77,11 @@ WORKLOADS = {
                n_datasets=1),
     "c2": dict(n_static=14, windows=None, T=100_000, max_episode_duration=500, envs=4_096,
                n_datasets=1),
+    # config 4: 262 144 envs sharded over 8 GPUs = 32 768 envs per GPU (kept per GPU at any --gpus:
+    # weak scaling), the single dataset replicated, RCCL all-gather of the returns AND of the
+    # observations (what BASELINE config 4 names; --no-gather-obs measures it without)
+    "c4": dict(n_static=30, windows=20, T=100_000, max_episode_duration=500, envs=32_768,
+               n_datasets=1, gather_obs=True),
     # config 5: 1 024 symbols x 256 envs over 8 GPUs = 128 resident datasets and 32 768
     # envs per GPU, per-env dataset indirection, switch at every episode
     "c5": dict(n_static=30, windows=20, T=100_000, max_episode_duration=500, envs=32_768,
@@ -249,33 +260,79 @@ def recorded_traffic(workload, N):
 
 
 def roofline_block(N, kernel_us, shape, traffic):
+    """`achieved` is a PHYSICAL rate: the PMC traffic of one launch / its duration when counters
+    exist, else the compulsory bytes / duration (`achieved_is` says which); `frac` = achieved /
+    peak always.  The SURVEY §8d algorithmic figure (no reuse of the table credited: with the
+    table served from L2 it exceeds what the memory system moves, and the peak) is kept as
+    `achieved_algorithmic` / `frac_algorithmic` only.  `frac_compulsory` — useful bytes only — and
+    `traffic_over_compulsory` — wasted re-reads — are reported for every workload: a kernel that
+    moves 1.9x its compulsory bytes at a high rate (config 5) shows a high `frac` and a low
+    `frac_compulsory`."""
     W, F_obs, F_s, n_dyn = shape
     b_alg, b_min = algorithmic_bytes(*shape), compulsory_bytes(*shape)
     secs = kernel_us * 1e-6
-    achieved = b_alg * N / secs / 1e9
+    alg_rate = b_alg * N / secs / 1e9
+    min_rate = b_min * N / secs / 1e9
     obs_bytes = 4 * W * F_obs * N
-    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    in_mall = obs_bytes <= (190 << 20)
+    r = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": None, "traffic": None,
-         "frac_algorithmic": achieved / HBM_PEAK_GBS,
-         "frac_compulsory": b_min * N / secs / 1e9 / HBM_PEAK_GBS,
+         "frac_compulsory": min_rate / HBM_PEAK_GBS, "traffic_over_compulsory": None,
+         "achieved_is": None,
+         "achieved_algorithmic": alg_rate, "frac_algorithmic": alg_rate / HBM_PEAK_GBS,
          "algorithmic_bytes_per_env_step": b_alg, "compulsory_bytes_per_env_step": b_min,
          "kernel_us_per_launch": kernel_us,
          "regime": ("infinity-cache: %.0f MB of observations per launch stay in the 256 MiB MALL "
-                    "(sc1 stores); counters = fabric traffic" % (obs_bytes / 1e6)
-                    if obs_bytes <= (190 << 20) else
-                    "hbm: %.0f MB of observations per launch stream to DRAM (non-temporal stores)"
-                    % (obs_bytes / 1e6))}
+                    "(sc1 stores); FETCH/WRITE_SIZE count MALL hits, so `achieved` is a FABRIC "
+                    "(Infinity Cache) rate measured against the HBM peak, not a DRAM rate"
+                    % (obs_bytes / 1e6) if in_mall else
+                    "hbm: %.0f MB of observations per launch stream to DRAM (non-temporal stores); "
+                    "`achieved` is a DRAM rate against the HBM peak" % (obs_bytes / 1e6))}
     if traffic:
         rate = traffic["bytes_per_launch"] / secs / 1e9
-        r.update(traffic=traffic["bytes_per_launch"], traffic_rate=rate,
-                 traffic_frac=rate / HBM_PEAK_GBS, frac=rate / HBM_PEAK_GBS,
+        r.update(achieved=rate, frac=rate / HBM_PEAK_GBS, traffic=traffic["bytes_per_launch"],
+                 achieved_is="PMC traffic (FETCH_SIZE x2 + WRITE_SIZE) per launch / kernel time",
                  traffic_fetch_bytes=traffic["fetch_bytes"], traffic_write_bytes=traffic["write_bytes"],
                  traffic_over_compulsory=traffic["bytes_per_launch"] / (b_min * N),
                  traffic_source=traffic["source"], kernel=traffic.get("kernel"))
-    else:  # no counters: the compulsory-byte fraction is the only physical one available
-        r["frac"] = r["frac_compulsory"]
-        r["frac_is"] = "frac_compulsory (no PMC counters available)"
+    else:  # no counters: the compulsory bytes are the only physical count available
+        r.update(achieved=min_rate, frac=min_rate / HBM_PEAK_GBS,
+                 achieved_is="compulsory bytes per launch / kernel time (no PMC counters available)")
     return r
+
+
+# ---------------------------------------------------------------------------------------
+# --gpus N from a bare shell: start the ranks as fresh children
+
+def self_launch(argv, n_gpus):
+    """`python3 bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): start the N
+    ranks as CHILD processes — `python -m torch.distributed.run --nproc-per-node N bench.py ...`,
+    before this process has imported torch or touched the GPU (never an exec) — relay rank 0's
+    ONE JSON line, and exit non-zero if any rank failed.  Under an external torchrun (the
+    driver's way) WORLD_SIZE is set and this is not used."""
+    import socket
+    with socket.socket() as so:  # a free rendezvous port
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes: dmabuf IPC only
+    print(f"[bench] --gpus {n_gpus} without a launcher: starting {' '.join(cmd)}", file=sys.stderr)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:  # everything but the JSON line goes to stderr, like in a rank
+        if out.lstrip().startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc != 0 or line is None:
+        print(f"[bench] the {n_gpus}-rank run failed (exit code {rc}, JSON line "
+              f"{'missing' if line is None else 'present'})", file=sys.stderr)
+        raise SystemExit(rc or 1)
+    print(line, flush=True)
+    raise SystemExit(0)
 
 
 def main():
@@ -300,7 +357,13 @@ def main():
     ap.add_argument("--no-hbm-regime", action="store_true",
                     help="skip the 262 144-env leg (observations streamed to HBM)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--gather-obs", action="store_true", help="also all-gather observations (N>1)")
+    ap.add_argument("--gather-obs", action="store_true",
+                    help="also all-gather the observations after every step (N>1; xGMI-bound: 2 560 B "
+                         "per env).  Workload c4 does by default — BASELINE config 4 names it — and "
+                         "also reports the same run WITHOUT it (config.without_obs_gather)")
+    ap.add_argument("--no-gather-obs", action="store_true",
+                    help="c4: measure `value` without the observation all-gather (the run with it is "
+                         "then reported under config.with_obs_gather)")
     ap.add_argument("--gather-mode", default="auto",
                     choices=["auto", "step", "step-overlap", "block", "torch-step"],
                     help="N>1, the mode `value` is measured in: 'step' = synchronous per-step "
@@ -332,6 +395,8 @@ def main():
         from oracle.py_loop import time_loop
         print(time_loop(seconds=args.cpu_python_loop)[0])
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
+        self_launch(sys.argv[1:], args.gpus)  # children first: this process never touches the GPU
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a
     # version banner at communicator creation), so everything but that line goes to stderr.
     sys.stdout.flush()
@@ -388,7 +453,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)  # RCCL over xGMI
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py bare (it launches "
+                         f"its own ranks) or under torchrun with --nproc-per-node {args.gpus}")
+    # the observation all-gather: asked for, or part of the workload (c4)
+    want_obs = use_dist and (args.gather_obs or (bool(wl.get("gather_obs")) and not args.no_gather_obs))
+    both_obs = use_dist and bool(wl.get("gather_obs")) and not args.gather_obs  # c4 reports both
 
     modes = []
     if use_dist:
@@ -424,7 +494,7 @@ def main():
         if any(m in ("step", "step-overlap") for m in modes):
             from gym_trading_env_amd.distributed import NativeReturnGather
             try:
-                comm = NativeReturnGather(env, with_obs=args.gather_obs, mode=1)  # libgte's own communicator
+                comm = NativeReturnGather(env, with_obs=want_obs or both_obs, mode=1)  # libgte's own communicator
                 ok = torch.ones(1, device=dev)
             except Exception as e:  # noqa: BLE001 - RCCL not loadable / communicator refused
                 print(f"[bench] rank {rank}: libgte's RCCL communicator unavailable ({e!r}); "
@@ -436,13 +506,14 @@ def main():
                     comm.close()
                     comm = None
                 modes = [("torch-step" if m == "step" else m) for m in modes if m != "step-overlap"]
-        returns = ReturnGather(N, dev, obs_shape=env.obs_shape if args.gather_obs else None,
+        returns = ReturnGather(N, dev, obs_shape=env.obs_shape if (want_obs or both_obs) else None,
                                depth=depth, block=block)
         returns1 = ReturnGather(N, dev)  # torch-step: plain synchronous gather
         pipe = ReturnPipeline(env, returns, block, depth)
 
-    def timed(mode, first_step):
+    def timed(mode, first_step, with_obs=None):
         """W warm-up + K timed steps with the returns gathered the `mode` way -> (wall s, event ms)."""
+        with_obs = want_obs if with_obs is None else with_obs
         def one_step(i):
             if mode == "block":
                 pipe.before_step()  # rows about to be rewritten must have been gathered
@@ -459,7 +530,7 @@ def main():
                 comm.gather()
             elif mode == "torch-step":
                 returns1.gather(env.packed_returns)
-            if mode is not None and args.gather_obs:
+            if mode is not None and with_obs:
                 (comm.gather_obs() if mode in ("step", "step-overlap") else returns.gather_obs(obs))
 
         def drain():
@@ -512,6 +583,10 @@ def main():
     for k, m in enumerate(modes[1:]):
         e2, _ = timed(m, (k + 1) * (args.warmup + args.steps))
         other_modes[m] = {"ms_per_step": e2 * 1e3 / args.steps, "value": world * N * args.steps / e2}
+    other_obs = None
+    if both_obs and mode is not None:  # c4: the same run with the observation gather switched
+        e3, _ = timed(mode, (len(modes) + 1) * (args.warmup + args.steps), with_obs=not want_obs)
+        other_obs = {"ms_per_step": e3 * 1e3 / args.steps, "value": world * N * args.steps / e3}
 
     # (episodes really end inside the timed region: auto-reset is part of the step)
     info = env.launch_info()
@@ -549,13 +624,20 @@ def main():
                                "next step (gte_allgather_returns mode 1): global returns one step late",
                "torch-step": ", synchronous per step (torch.distributed)"}
         if use_dist:
-            par += " + RCCL all-gather(reward,flags" + (",obs)" if args.gather_obs else ")") + how[mode]
+            par += " + RCCL all-gather(reward,flags" + (",obs)" if want_obs else ")") + how[mode]
+        D = wl["n_datasets"]
+        what = f"{args.workload}: {N} envs/GPU x obs ({W},{F_obs}) f32, "
+        if args.workload == "c4":
+            what = (f"c4: {N} envs/GPU (262 144 envs sharded over 8 GPUs; {world * N} global here) x obs "
+                    f"({W},{F_obs}) f32, returns " + ("AND observations all-gathered over xGMI"
+                                                     if want_obs else "all-gathered, observations kept local")
+                    + " after every step, ")
         out = {
             "metric": "env-steps/sec", "value": world * N * args.steps / el, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {N} envs/GPU x obs ({W},{F_obs}) f32, "
+            "config": {"workload": what +
                                    f"{wl['n_datasets']} dataset(s)/GPU of T={wl['T']}, positions [-1,0,1], "
                                    f"fees 1e-4, borrow 3e-6, max_episode_duration {cycle}, next-step autoreset",
                        "envs_per_gpu": N, "global_envs": world * N, "parallelism": par,
@@ -563,14 +645,22 @@ def main():
                                          if args.sync_episodes else
                                          "staggered by an untimed prologue: ~N/%d episode ends and "
                                          "auto-resets in every step" % cycle),
-                       "launch": info, "episodes_finished": episodes},
+                       "launch": info, "episodes_finished": episodes,
+                       "datasets": ("one dataset, replicated on every rank" if D == 1 else
+                                    f"{world * D} symbols partitioned by rank: rank r keeps symbols "
+                                    f"{D}r .. {D}r+{D - 1} resident and its {N} envs only ever visit those "
+                                    f"(per-env dataset_index, switch at every episode); no remote reads")},
             "roofline": roofline_block(N, kernel_us, shape,
                                        live.get(N) or recorded_traffic(args.workload, N)),
         }
         if other_modes:  # the same run with the returns gathered the other ways
             out["config"]["other_gather_modes"] = {
                 m: dict(v, parallelism=f"env-shard x{world} + RCCL all-gather(reward,flags"
-                        + (",obs)" if args.gather_obs else ")") + how[m]) for m, v in other_modes.items()}
+                        + (",obs)" if want_obs else ")") + how[m]) for m, v in other_modes.items()}
+        if other_obs:
+            out["config"]["without_obs_gather" if want_obs else "with_obs_gather"] = dict(
+                other_obs, parallelism=f"env-shard x{world} + RCCL all-gather(reward,flags"
+                + (")" if want_obs else ",obs)") + how[mode])
         if hbm:
             out["roofline"]["hbm_regime"] = hbm
         if world == 1 and not args.no_cpu_baseline:

@@ -490,7 +490,7 @@ class BatchedTradingEnv(_VectorEnvBase):
         elif name == "position":
             t = self._positions_table()[f("position_index").long()]
         elif name == "reward":
-            return v  # the step's reward already is the terminal step's
+            t = self._t["reward64"]  # the terminal step's reward (the log row under it is a reset row: 0)
         elif name == "date" or name.startswith("data_"):
             t = self._dataset_column(name, f("dataset_index"), f("idx"))
             if not isinstance(t, torch.Tensor):  # host column (dates, objects)
@@ -725,6 +725,7 @@ class BatchedTradingEnv(_VectorEnvBase):
             for key, name in (("asset", "asset"), ("fiat", "fiat"), ("ia", "interest_asset"),
                               ("ifi", "interest_fiat")):
                 port[key][n - 1] = fs(name)[e]
+            bufs["rew"][n - 1] = self.read_output("reward64")[e]  # (the reset row under it logs 0)
         step = bufs["step"][:n]
         # the episode = the last run of rows whose step counts 0, 1, 2, ...
         start = n - 1

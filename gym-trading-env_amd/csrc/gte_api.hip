@@ -743,7 +743,9 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
     p.log = E->log;
     p.log_row_base = (E->log_rows % E->cfg.log_steps) * (int64_t)p.N;
   }
-  const bool hot = E->vec == 4 && E->coop && E->stage == 1 && !(E->cfg.kernel_variant & 64) && !fused_log;
+  // (hot_tu_covers: the isolated instantiations have no terminal records and no trajectory row)
+  const bool hot = E->vec == 4 && E->coop && E->stage == 1 && !(E->cfg.kernel_variant & 64) &&
+                   gte::hot_tu_covers(p);
   if (hot && E->cfg.nontemporal_obs == 2)
     HIPCHK(gte::launch_step_hot(p, E->blocks, E->threads, gte::lds_bytes(p, E->stage), E->stream));
   else if (hot && E->cfg.nontemporal_obs == 1)
@@ -1233,17 +1235,28 @@ int gte_comm_init(gte_env* E, const uint8_t* id, int32_t rank, int32_t world) {
   if (r != 0) { E->comm = nullptr; return fail(GTE_ERR_HIP, "ncclCommInitRank: %s", gte::rccl_error(r)); }
   E->comm_rank = rank;
   E->comm_world = world;
-  HIPCHK(hipStreamCreateWithFlags(&E->comm_stream, hipStreamNonBlocking));
-  HIPCHK(hipEventCreateWithFlags(&E->comm_ready, hipEventDisableTiming));
-  for (auto& ev : E->comm_done) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  if (E->gathered_returns) {  // a communicator of another size was here before
-    for (void*& q : E->allocs) if (q == (void*)E->gathered_returns) q = nullptr;
-    (void)hipFree(E->gathered_returns);
-    E->gathered_returns = nullptr;
+  // anything failing from here on must not leave a half-made communicator behind (a retry would
+  // be refused with "already has a communicator"): undo everything, keep the error message
+  auto finish = [&]() -> int {
+    HIPCHK(hipStreamCreateWithFlags(&E->comm_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&E->comm_ready, hipEventDisableTiming));
+    for (auto& ev : E->comm_done) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (E->gathered_returns) {  // a communicator of another size was here before
+      for (void*& q : E->allocs) if (q == (void*)E->gathered_returns) q = nullptr;
+      (void)hipFree(E->gathered_returns);
+      E->gathered_returns = nullptr;
+    }
+    TRY(dev_alloc(E, &E->gathered_returns, (size_t)world * 6 * (size_t)E->p.N));
+    HIPCHK(hipDeviceSynchronize());
+    return GTE_OK;
+  };
+  const int rc = finish();
+  if (rc != GTE_OK) {
+    const std::string keep = g_err;
+    (void)gte_comm_destroy(E);
+    g_err = keep;
   }
-  TRY(dev_alloc(E, &E->gathered_returns, (size_t)world * 6 * (size_t)E->p.N));
-  HIPCHK(hipDeviceSynchronize());
-  return GTE_OK;
+  return rc;
 }
 
 int gte_allgather(gte_env* E, const void* src_device, void* dst_device, uint64_t bytes_per_rank,
@@ -1306,7 +1319,7 @@ int gte_comm_destroy(gte_env* E) {
   if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
   if (!E->comm) return GTE_OK;
   (void)hipStreamSynchronize(E->stream);
-  (void)hipStreamSynchronize(E->comm_stream);
+  if (E->comm_stream) (void)hipStreamSynchronize(E->comm_stream);
   const int r = gte::rccl_comm_destroy(E->comm);
   E->comm = nullptr;
   if (E->comm_ready) (void)hipEventDestroy(E->comm_ready);

@@ -15,7 +15,10 @@ __global__ void gte_log_kernel(const EnvRec* rec, const double* reward64, const 
   const EnvRec r = rec[e];
   const int64_t k = row_base + e;
   o.idx[k] = r.idx; o.step[k] = r.step; o.pos[k] = r.pos; o.dsi[k] = r.dsi;
-  o.pv[k] = r.pv; o.realpos[k] = r.realpos; o.reward[k] = reward64[e];
+  // a row a reset wrote carries reward 0 (environments.py:196) — also when the reset ran inside
+  // the step that ended the episode (same-step mode: the terminal step's reward is in the return
+  // buffers and in final_info, this row already describes the new episode)
+  o.pv[k] = r.pv; o.realpos[k] = r.realpos; o.reward[k] = (r.step == 0) ? 0.0 : reward64[e];
   o.asset[k] = r.asset; o.fiat[k] = r.fiat; o.ia[k] = r.ia; o.ifi[k] = r.ifi;
   o.flags[k] = (uint8_t)((term[e] ? 1 : 0) | (trunc[e] ? 2 : 0));
 }
@@ -94,7 +97,8 @@ hipError_t launch_set_dynamic_columns(const Params& p, const void* const* cols, 
 // reset wrote carry reward 0) and the three places the value lives — the f64 and f32 return
 // buffers and the newest row of the trajectory log (`historical_info["reward", -1] = reward`).
 // terminal_view (same-step auto-reset): an env that ended shows its TERMINAL row to the callable,
-// so the reset row underneath does not zero its reward.
+// so the reset row underneath does not zero the reward it RETURNS; the log row itself — the reset
+// row of the next episode — keeps the reference's 0.
 __global__ void gte_apply_reward_kernel(const Params p, const double* reward, const int32_t* log_step_row,
                                         double* log_reward_row, int terminal_view) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -106,7 +110,7 @@ __global__ void gte_apply_reward_kernel(const Params p, const double* reward, co
   const double r = (term || reset_row) ? 0.0 : reward[e];
   p.reward64[e] = r;
   p.reward[e] = (float)r;
-  log_reward_row[e] = r;
+  log_reward_row[e] = (log_step_row[e] == 0) ? 0.0 : r;  // the log row of a reset keeps reward 0 (:196)
 }
 
 hipError_t launch_apply_reward(const Params& p, const double* reward, const int32_t* log_step_row,

@@ -99,6 +99,16 @@ struct Params {
   int64_t log_row_base;  // index of env 0 in the row being written: (row % L) * N
 };
 
+// What the ISOLATED hot instantiations of the step kernel (gte_hot.hip / gte_hot_nt.hip, compiled
+// with GTE_HOT_ONLY) leave OUT of phase A: the terminal records behind `final_info`
+// (p.final_rec, environments.py:272 in same-step mode) and the trajectory row written by the
+// kernel itself (p.log).  This is the ONE statement of that list: gte_step picks the kernel with
+// it, the hot launchers refuse any launch it does not cover (hipErrorInvalidValue -> GTE_ERR_HIP),
+// and every `#ifndef GTE_HOT_ONLY` block inside phase A names a field tested here.  Round 2
+// shipped a launch predicate that had drifted from the compiled-out store: final_info read
+// zero-filled records at every 16-byte-vector shape.
+inline bool hot_tu_covers(const Params& p) { return p.final_rec == nullptr && p.log.idx == nullptr; }
+
 // ---------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011).  One block of four draws per
 // (global env id, episode, stream).  The reference draws from NumPy's global

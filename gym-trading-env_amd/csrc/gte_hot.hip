@@ -19,6 +19,7 @@ namespace gte {
 
 hipError_t GTE_HOT_NAME(launch_step_hot)(const Params& p, int blocks, int threads, size_t smem,
                                          hipStream_t stream) {
+  if (!hot_tu_covers(p)) return hipErrorInvalidValue;  // features compiled out of this TU (gte_device.h)
   const uint32_t V = (uint32_t)(p.W * p.Fobs);
   auto magic = [](uint32_t d) { return ((1ull << 40) + d - 1) / d; };
   const uint64_t vm = magic(V / 4), fm = magic((uint32_t)p.Fobs / 4),

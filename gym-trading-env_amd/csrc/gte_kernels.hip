@@ -21,8 +21,9 @@
 // Kernels:  gte_kernel<MODE,...>     phase A, LDS barrier, gather: every step and reset
 //                                    (the headline instantiation is compiled alone in
 //                                    gte_hot.hip / gte_hot_nt.hip);
-//           gte_rollout_kernel       K steps in one launch, windows resident in LDS
-//                                    (gte_rollout.hip);
+//           gte_rollout.hip          K steps in one launch: gte_rollout_resident_kernel (windows
+//                                    resident in LDS), gte_rollout_state_kernel (no observations),
+//                                    gte_rollout_kernel (gather per step; shapes LDS cannot hold);
 //           gte_affinity_*           counting sort of the envs by table region
 //                                    (processing order, speed only);
 //           gte_add_orders / gte_extract_state / gte_rewind_queue: small helpers.
@@ -387,7 +388,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
       if (ended && p.autoreset == GTE_AUTORESET_SAME_STEP) {
         // the reference's step() runs _get_obs (:272) before any wrapper resets the env:
         // write the terminal row's dynamic features, remember the terminal window
-#ifndef GTE_HOT_ONLY  // (the isolated hot instantiations never run with final_obs)
+#ifndef GTE_HOT_ONLY  // p.final_rec: hot_tu_covers() keeps such launches off the isolated TUs
         if (p.final_rec) {  // what the wrapper's `final_info` reports (state before the reset)
           store_state_at(&p.final_rec[e], s);
           p.final_rec[e].start = s.start;
@@ -814,7 +815,7 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
     const int e = active ? (p.perm ? p.perm[wg_first + s] : wg_first + s) : 0;
     ObsJob job;
     FinalJob fin;
-#ifndef GTE_HOT_ONLY  // (the isolated hot instantiations never write the trajectory row)
+#ifndef GTE_HOT_ONLY  // p.log: hot_tu_covers() keeps such launches off the isolated TUs
     if (MODE == MODE_STEP && p.log.idx) {
       // gte_step with log_steps: the lane that stepped the env also writes its trajectory row —
       // what History.add records (environments.py:253-264) — from its registers, instead of a
@@ -825,7 +826,7 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
       if (active) {
         const int64_t k = p.log_row_base + e;
         p.log.idx[k] = so.idx; p.log.step[k] = so.step; p.log.pos[k] = so.pos; p.log.dsi[k] = so.dsi;
-        p.log.pv[k] = so.pv; p.log.realpos[k] = so.realpos; p.log.reward[k] = so.reward;
+        p.log.pv[k] = so.pv; p.log.realpos[k] = so.realpos; p.log.reward[k] = (so.step == 0) ? 0.0 : so.reward;  // reset rows: 0 (:196)
         p.log.asset[k] = so.asset; p.log.fiat[k] = so.fiat; p.log.ia[k] = so.ia; p.log.ifi[k] = so.ifi;
         p.log.flags[k] = (uint8_t)so.flags;
       }

@@ -497,6 +497,7 @@ __global__ __launch_bounds__(256) void gte_rollout_state_kernel(const Params p0,
 
 hipError_t launch_rollout_state(const Params& p, const RolloutArgs& r, int n_steps, int epw,
                                 hipStream_t stream) {
+  if (!hot_tu_covers(p)) return hipErrorInvalidValue;  // this TU is compiled with GTE_HOT_ONLY (gte_device.h)
   const int waves = (p.N + epw - 1) / epw;
   hipLaunchKernelGGL(gte_rollout_state_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, p, r, n_steps, epw);
   return hipGetLastError();
@@ -542,6 +543,7 @@ int resident_blocks_per_cu(const Params& p, int epb, int nt) {
 
 hipError_t launch_rollout_resident(const Params& p, const RolloutArgs& r, int nt, int blocks,
                                    hipStream_t stream) {
+  if (!hot_tu_covers(p)) return hipErrorInvalidValue;  // this TU is compiled with GTE_HOT_ONLY (gte_device.h)
   const size_t smem = resident_lds_bytes(p, r.epb);
   auto magic = [](uint32_t d) { return ((1ull << 40) + d - 1) / d; };
   const uint32_t FV = (uint32_t)p.Fobs / 4u;
@@ -575,6 +577,7 @@ int rollout_blocks_per_cu(const Params& p, int nt) {
 
 hipError_t launch_rollout(const Params& p, const RolloutArgs& r, int nt, int blocks, int threads,
                           hipStream_t stream) {
+  if (!hot_tu_covers(p)) return hipErrorInvalidValue;  // this TU is compiled with GTE_HOT_ONLY (gte_device.h)
   const size_t smem = rollout_lds_bytes(p);
   const uint32_t V = (uint32_t)(p.W * p.Fobs);
   auto magic = [](uint32_t d) { return ((1ull << 40) + d - 1) / d; };

@@ -37,7 +37,9 @@ class EnvInfo(dict):
     `portfolio_valuation`, ... — `info_keys`) are read from the step's shared column arrays on
     access instead of being copied into N dicts per step; the keys SB3 itself looks for
     (`terminal_observation`, `TimeLimit.truncated`, `episode` ...) are ordinary stored items, set
-    only for the envs whose episode ended.  A view of the CURRENT step: values change with the
+    only for the envs whose episode ended — for those the History scalars are stored items too,
+    holding the TERMINAL step's values (what DummyVecEnv over the reference returns,
+    environments.py:272), since the shared columns already describe the next episode.  A view of the CURRENT step: values change with the
     next step (use `dict(info)` / `info.copy()` to keep one)."""
     __slots__ = ("_c", "_i")
 
@@ -58,13 +60,13 @@ class EnvInfo(dict):
         return dict.__contains__(self, k) or k in self._c.cols
 
     def keys(self):
-        return list(self._c.cols) + list(dict.keys(self))
+        return list(self._c.cols) + [k for k in dict.keys(self) if k not in self._c.cols]
 
     def __iter__(self):
         return iter(self.keys())
 
     def __len__(self):
-        return len(self._c.cols) + dict.__len__(self)
+        return len(self.keys())
 
     def items(self):
         return [(k, self[k]) for k in self.keys()]
@@ -136,10 +138,19 @@ class SB3TradingVecEnv(_Base):
             dict.clear(infos[e])
         self._dirty = []
         if dones.any():
-            ids, last = self.env.final_observations()
+            env = self.env
+            ids, last = env.final_observations()
+            # DummyVecEnv over the reference returns the TERMINAL step's info for an env that ended
+            # (environments.py:272), with terminal_observation added; the shared columns already
+            # describe the episode the in-launch reset started, so the terminal values (from the
+            # terminal records, gte_get_final_state) are stored in the dict, shadowing the columns
+            r64 = env.read_output("reward64") if "reward" in self.info_keys else None
+            final = {k: np.asarray(env._info_value(k, env.final_state, r64))[ids] for k in self.info_keys}
             ids, last = ids.tolist(), self._host(last)
-            for e, o in zip(ids, last):
+            for j, (e, o) in enumerate(zip(ids, last)):
                 d = infos[e]
+                for k, col in final.items():
+                    dict.__setitem__(d, k, col[j])
                 dict.__setitem__(d, "terminal_observation", o)
                 dict.__setitem__(d, "TimeLimit.truncated", bool(truncated[e] and not terminated[e]))
             self._dirty = ids

@@ -298,3 +298,26 @@ def test_two_rank_sharded_run_equals_unsharded(tmp_path, oracle_mod):
         np.testing.assert_array_equal(got["obs"][k], env.obs)
         ends += int(env.truncated.sum() + env.terminated.sum())
     assert ends > G  # episodes ended and were re-drawn from the per-global-id streams
+
+
+def test_bench_gpus_n_launches_its_own_ranks_and_relays_their_failure():
+    """`python3 bench.py --gpus 2` from a bare shell (WORLD_SIZE unset) starts two rank
+    processes under torch.distributed.run as CHILDREN, before touching the GPU itself.  Here
+    (no GPU) every rank refuses to run — there is no CPU fallback — and the parent must relay
+    that: non-zero exit, no JSON line on stdout."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU host: the working path is tests/test_gpu_distributed.py")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--no-pmc", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "--gpus 2 without a launcher" in r.stderr
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr
+    assert r.stderr.count("bench.py needs an MI355X") >= 1  # the ranks started and said why
+    assert '{"metric"' not in r.stdout

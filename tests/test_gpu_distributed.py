@@ -285,3 +285,31 @@ def test_two_ranks_on_one_gpu_equal_unsharded_oracle(tmp_path, oracle_mod):
         np.testing.assert_array_equal(g["reward"][k], ora.reward)
         np.testing.assert_array_equal(g["term"][k], ora.terminated.astype(bool))
         np.testing.assert_array_equal(g["trunc"][k], ora.truncated.astype(bool))
+
+
+def test_bench_gpus_2_from_a_bare_shell_launches_its_own_ranks():
+    """`python3 bench.py --gpus 2` without a launcher around it: the parent starts the two ranks
+    as fresh child processes (torch.distributed.run) before touching the GPU, relays rank 0's ONE
+    JSON line and exits 0.  Rehearsal configuration of a one-GPU box: both ranks share device 0
+    and exchange their returns over gloo (RCCL refuses two ranks on one device)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GTE_BENCH_BACKEND="gloo", GTE_BENCH_SHARE_DEVICE="1")
+    for workload, extra in (("c3", ["--envs", "8192"]), ("c4", ["--envs", "4096"])):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20",
+                            "--warmup", "5", "--workload", workload, "--no-cpu-baseline", "--no-pmc"] + extra,
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, r.stdout
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5
+        assert out["config"]["global_envs"] == 2 * out["config"]["envs_per_gpu"]
+        assert out["value"] > 0 and out["scaling"] == "weak"
+        if workload == "c4":  # BASELINE config 4: with the observation all-gather, and without beside it
+            assert "observations all-gathered" in out["config"]["workload"]
+            assert out["config"]["without_obs_gather"]["value"] >= out["value"] * 0.5

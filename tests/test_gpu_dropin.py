@@ -461,6 +461,7 @@ def test_sb3_vecenv_adapter_against_single_envs():
         a = rng.integers(0, 4, N)
         vec.step_async(a)
         obs, rewards, dones, infos = vec.step_wait()
+        pv_before = ora.state()["portfolio_valuation"].copy()
         ora.step(a.astype(np.int32))
         np.testing.assert_array_equal(obs, ora.obs)
         np.testing.assert_array_equal(rewards, ora.reward)
@@ -473,7 +474,17 @@ def test_sb3_vecenv_adapter_against_single_envs():
                 assert infos[e]["TimeLimit.truncated"] == bool(ora.truncated[e] and not ora.terminated[e])
                 seen_term += int(ora.terminated[e])
                 seen_trunc += int(ora.truncated[e] and not ora.terminated[e])
-            assert infos[e]["portfolio_valuation"] == ora.state()["portfolio_valuation"][e]
+            if not dones[e]:
+                assert infos[e]["portfolio_valuation"] == ora.state()["portfolio_valuation"][e]
+            elif ora.terminated[e]:
+                # an env that ended reports its TERMINAL step's info (environments.py:272), not the
+                # state after the in-launch reset (the oracle keeps no terminal record: the
+                # valuation is checked through the rules it obeyed; exact values against a
+                # non-resetting twin in test_gpu_vector_api.py)
+                assert infos[e]["portfolio_valuation"] / 1000 <= 0.7
+            else:
+                np.testing.assert_allclose(np.log(infos[e]["portfolio_valuation"] / pv_before[e]),
+                                           rewards[e], rtol=2e-6, atol=1e-9)
     assert seen_term > 0 and seen_trunc > 0
     assert vec.env_is_wrapped(object) == [False] * N and vec.get_attr("num_envs", [0, 1]) == [N, N]
     vec.close()

@@ -254,19 +254,26 @@ def test_batched_history_access_patterns():
         env.close()
 
 
-def test_same_step_final_observation_and_final_info():
+# (static features, windows, N): F_obs = static + 2.  F_obs % 4 == 0 takes the 16-byte-vector
+# kernels — the shapes people use (the headline is 30 + 2) and the ones round 2 never tested here:
+# its isolated hot instantiation skipped the terminal records `final_info` is served from.
+FINAL_SHAPES = [(4, 3, 200), (6, 8, 200), (6, 3, 200), (6, None, 200), (30, 20, 3000), (6, 16, 20000)]
+
+
+@pytest.mark.parametrize("Fs,windows,N", FINAL_SHAPES)
+def test_same_step_final_observation_and_final_info(Fs, windows, N):
     """Gymnasium's same-step convention (docs/source/vectorize_env.rst:25-33 + SURVEY §8f):
     the envs that end get `final_observation` / `final_info` (with masks) holding what
     TradingEnv.step returned for them before the reset — checked against a twin batch that does
     not auto-reset (same first episodes)."""
     import gym_trading_env_amd as gte
-    feat, close = _walk(33, 300, 4, sigma=3e-2, drift=-2e-3)
+    feat, close = _walk(33, 300, Fs, sigma=3e-2, drift=-2e-3)
     df = make_df(feat, close)
-    kw = dict(positions=[-2, -1, 0, 1, 2], windows=3, trading_fees=1e-3, borrow_interest_rate=1e-4,
+    kw = dict(positions=[-2, -1, 0, 1, 2], windows=windows, trading_fees=1e-3, borrow_interest_rate=1e-4,
               max_episode_duration=12, seed=8, output="numpy")
-    N = 200
     env = gte.BatchedTradingEnv(df, N, autoreset="same_step", final_obs=True, **kw)
     twin = gte.BatchedTradingEnv(df, N, autoreset=None, **kw)
+    assert env.launch_info()["vector_bytes"] == (16 if (Fs + 2) % 4 == 0 else 4)
     env.reset(); twin.reset()
     rng = np.random.default_rng(5)
     first_episode = np.ones(N, dtype=bool)
@@ -280,25 +287,31 @@ def test_same_step_final_observation_and_final_info():
         mask = info["_final_observation"]
         np.testing.assert_array_equal(mask, ended)
         np.testing.assert_array_equal(info["_final_info"], ended)
-        for e in np.nonzero(ended & first_episode)[0]:
+        for e in np.nonzero(ended & first_episode)[0][:400]:
             np.testing.assert_array_equal(info["final_observation"][e], o2[e])
             fi = info["final_info"][e]
             for key in ("idx", "step", "position_index", "position", "real_position",
                         "portfolio_valuation", "portfolio_distribution_asset",
-                        "portfolio_distribution_borrowed_fiat", "data_close", "data_volume", "date"):
+                        "portfolio_distribution_borrowed_fiat", "portfolio_distribution_interest_asset",
+                        "data_close", "data_volume", "date"):
                 assert fi[key] == i2[key][e], key
             assert fi["reward"] == r2[e] == reward[e]
             checked += 1
-        for e in np.nonzero(~ended)[0]:
+        for e in np.nonzero(~ended)[0][:400]:
             assert info["final_observation"][e] is None and info["final_info"][e] is None
-        first_episode &= ~ended
+        # same-step episode_metrics() reads the terminal records too (environments.py:279-286)
         m = env.episode_metrics()
         np.testing.assert_array_equal(m["env_ids"], np.nonzero(ended)[0])
-        if len(m["env_ids"]):
-            e = m["env_ids"][0]
-            if (ended & (first_episode | True))[e] and info["final_info"][e]["step"] == twin.state("step")[e]:
-                assert m["episode_length"][0] == info["final_info"][e]["step"] + 1
-    assert checked > N // 2
+        sel = first_episode[m["env_ids"]] if len(m["env_ids"]) else np.zeros(0, bool)
+        ids = m["env_ids"][sel]
+        np.testing.assert_array_equal(m["episode_length"][sel], twin.state("step")[ids] + 1)
+        np.testing.assert_array_equal(m["portfolio_return"][sel],
+                                      twin.state("portfolio_valuation")[ids] / 1000 - 1)
+        c = df["close"].to_numpy()
+        np.testing.assert_array_equal(m["market_return"][sel],
+                                      c[twin.state("idx")[ids]] / c[twin.state("start_idx")[ids]] - 1)
+        first_episode &= ~ended
+    assert checked >= min(N, 400) // 2
     env.close(); twin.close()
 
 
@@ -408,15 +421,132 @@ def test_sb3_vecenv_with_the_forks_python_reward_function():
     custom.close(); builtin.close()
 
 
-def test_same_step_finished_episode_history_and_custom_metrics():
+def test_python_reward_in_same_step_mode_on_a_big_batch_with_the_affinity_order():
+    """SB3's mode (same-step auto-reset) with a Python reward function at N > 16 384 on a
+    16-byte-vector shape with the L2-affinity order on: the trajectory row is then written by the
+    separate log launch and the callable's TERMINAL row comes from the terminal records alone
+    (`_overlay`).  Round 2 launched the isolated hot kernel here, which never wrote those
+    records: a truncated env's reward became log(0 / pv).  Equal to the device enum."""
+    import gym_trading_env_amd as gte
+
+    def reward_function(history):  # the fork's (luckymodel/envs/env.py:16-18)
+        log_return = np.log(history["portfolio_valuation", -1] / history["portfolio_valuation", -2])
+        return np.clip(log_return, -0.002, 0.005)
+
+    feat, close = _walk(46, 500, 6, sigma=3e-2, drift=-1e-3)
+    df = make_df(feat, close)
+    kw = dict(positions=[-1, 0, 1], windows=16, trading_fees=1e-3, borrow_interest_rate=1e-4,
+              max_episode_duration=15, seed=13)
+    N = 20000
+    custom = gte.SB3TradingVecEnv(df, N, reward_function=reward_function, **kw)
+    builtin = gte.SB3TradingVecEnv(df, N, reward_function=("clipped_log_return", 1.0, -0.002, 0.005), **kw)
+    assert custom.env.launch_info()["vector_bytes"] == 16
+    assert custom.env.cfg.log_steps == 2 and builtin.env.cfg.log_steps == 0
+    np.testing.assert_array_equal(custom.reset(), builtin.reset())
+    rng = np.random.default_rng(3)
+    ends = 0
+    for k in range(34):
+        a = rng.integers(0, 3, N)
+        o1, r1, d1, i1 = custom.step(a)
+        o2, r2, d2, i2 = builtin.step(a)
+        np.testing.assert_array_equal(o1, o2, err_msg=f"step {k}")
+        np.testing.assert_array_equal(d1, d2)
+        assert np.isfinite(r1).all()
+        np.testing.assert_allclose(r1, r2, rtol=1e-6, atol=1e-12, err_msg=f"step {k}")
+        ends += int(d1.sum())
+    assert ends > N
+    custom.close(); builtin.close()
+
+
+@pytest.mark.parametrize("Fs,windows", [(4, 6), (6, 8)])
+def test_sb3_infos_of_finished_envs_are_the_terminal_steps(Fs, windows):
+    """SB3's DummyVecEnv over the reference hands back the TERMINAL step's info
+    (environments.py:272) with `terminal_observation` added; the adapter's `infos[e]` of an env
+    that just ended must therefore show the terminal `idx` / `portfolio_valuation` / ..., not the
+    state after the in-launch reset.  Against a twin that does not auto-reset."""
+    import gym_trading_env_amd as gte
+    feat, close = _walk(47, 400, Fs, sigma=3e-2, drift=-1e-3)
+    df = make_df(feat, close)
+    kw = dict(positions=[-1, 0, 1], windows=windows, trading_fees=1e-3, borrow_interest_rate=1e-4,
+              max_episode_duration=11, seed=21)
+    keys = ("idx", "step", "position", "real_position", "portfolio_valuation", "data_close", "reward")
+    N = 150
+    vec = gte.SB3TradingVecEnv(df, N, info_keys=keys, **kw)
+    twin = gte.BatchedTradingEnv(df, N, autoreset=None, output="numpy", **kw)
+    vec.reset(); twin.reset()
+    rng = np.random.default_rng(4)
+    first = np.ones(N, bool)
+    checked = 0
+    for k in range(13):
+        a = rng.integers(0, 3, N).astype(np.int32)
+        obs, rew, dones, infos = vec.step(a)
+        o2, r2, t2, u2, i2 = twin.step(a)
+        for e in np.nonzero(dones & first)[0]:
+            np.testing.assert_array_equal(infos[e]["terminal_observation"], o2[e])
+            for key in keys:
+                assert infos[e][key] == i2[key][e], (k, e, key)
+            assert infos[e].get("idx") == i2["idx"][e] and dict(infos[e])["step"] == i2["step"][e]
+            checked += 1
+        for e in np.nonzero(~dones & first)[0][:20]:  # running envs: the current step's info
+            assert infos[e]["idx"] == i2["idx"][e] and infos[e]["portfolio_valuation"] == i2["portfolio_valuation"][e]
+        first &= ~dones
+    assert checked >= N
+    # the step after: the dicts of the envs that ended are views of the running episode again
+    obs, rew, dones, infos = vec.step(rng.integers(0, 3, N).astype(np.int32))
+    np.testing.assert_array_equal([infos[e]["idx"] for e in range(N)], vec.env.state("idx"))
+    vec.close(); twin.close()
+
+
+@pytest.mark.parametrize("Fs", [3, 6])
+def test_reset_rows_of_the_log_carry_reward_zero_in_same_step_mode(Fs):
+    """The reference's reset row has reward 0 (environments.py:196).  In same-step mode the log
+    row of a step that ended an episode already describes the NEXT episode's reset row: its
+    reward must be 0 (the terminal step's reward lives in the return buffers and `final_info`),
+    so that one step later `h["reward", -2]` and `h["reward", 0]` read 0 like a reference History."""
+    import torch
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    from gym_trading_env_amd.device_array import DeviceArray
+    host = lambda x: x.numpy() if isinstance(x, DeviceArray) else np.asarray(x)
+    feat, close = _walk(48, 300, Fs, sigma=2e-2)
+    N = 500
+    for variant in (1024, 2048):  # separate log launch / row written by the step kernel
+        env = BatchedTradingEnv((feat, close), N, positions=[-1, 0, 1], windows=4, trading_fees=1e-3,
+                                max_episode_duration=7, seed=3, autoreset="same_step", final_obs=True,
+                                log_steps=16, kernel_variant=variant)
+        env.reset()
+        g = torch.Generator(device="cuda").manual_seed(5)
+        seen = 0
+        prev_ended = None
+        for k in range(20):
+            act = torch.randint(0, 3, (N,), dtype=torch.int32, device="cuda", generator=g)
+            _, reward, term, trunc, _ = env.step(act)
+            h = env.batched_history()
+            ended = (term | trunc).cpu().numpy()
+            assert (host(h["reward", -1])[ended] == 0).all()  # the row under an ended env is a reset row
+            np.testing.assert_array_equal(host(h["step", -1])[ended], 0)
+            if prev_ended is not None and prev_ended.any():
+                m = prev_ended & ~ended
+                assert (host(h["reward", -2])[m] == 0).all() and (host(h["reward", 0])[m] == 0).all()
+                seen += int(m.sum())
+            # the terminal view shows the terminal step's reward as the newest one
+            rt = host(env.batched_history(terminal=True)["reward", -1])
+            np.testing.assert_array_equal(rt[ended], env.read_output("reward64")[ended])
+            np.testing.assert_array_equal(rt[~ended], host(h["reward", -1])[~ended])
+            prev_ended = ended
+        assert seen > N
+        env.close()
+
+
+@pytest.mark.parametrize("Fs,windows", [(3, 3), (6, 8), (6, None)])
+def test_same_step_finished_episode_history_and_custom_metrics(Fs, windows):
     """Same-step auto-reset (SB3's mode) with a device log: `history(e, finished=True)` is the
     episode that just ended — terminal row included — and `episode_metrics()` evaluates
     `add_metric` functions on it (environments.py:274-286); checked against a twin batch that does
     not reset (same first episodes)."""
     import gym_trading_env_amd as gte
-    feat, close = _walk(55, 300, 3, sigma=2e-2)
+    feat, close = _walk(55, 300, Fs, sigma=2e-2)
     df = make_df(feat, close)
-    kw = dict(positions=[-1, 0, 1], windows=3, trading_fees=1e-3, max_episode_duration=9, seed=2,
+    kw = dict(positions=[-1, 0, 1], windows=windows, trading_fees=1e-3, max_episode_duration=9, seed=2,
               output="numpy", log_steps=32)
     N = 64
     env = gte.BatchedTradingEnv(df, N, autoreset="same_step", final_obs=True, **kw)
@@ -489,7 +619,10 @@ def test_apply_reward_and_dynamic_columns_entry_points():
             torch.cuda.synchronize()
             assert torch.equal(b._t["reward64"], want)
             assert torch.equal(b._t["reward"], want.to(torch.float32))
-            assert torch.equal(b._log_tensor("reward")[newest], want)
+            # the log row of a reset — in same-step mode also under an env that just ended — keeps
+            # the reference's reward 0 (environments.py:196)
+            assert torch.equal(b._log_tensor("reward")[newest],
+                               torch.where(a._log_tensor("step")[newest] == 0, torch.zeros_like(r), want))
             # dynamic columns: feature 0 from an f64 column, feature 1 from an f32 column
             c0 = torch.randn(N, dtype=torch.float64, device="cuda", generator=g)
             c1 = torch.randn(N, dtype=torch.float32, device="cuda", generator=g)

@@ -220,6 +220,38 @@ def test_kernel_register_budget(source, min_occupancy):
         assert k["occupancy"] >= min_occupancy, k
 
 
+def test_features_compiled_out_of_the_hot_translation_units_are_guarded():
+    """The isolated hot instantiations (GTE_HOT_ONLY) leave features out of phase A.  Every such
+    block must name the Params field it depends on, that field must be tested by
+    `hot_tu_covers` (gte_device.h), `gte_step` must pick the kernel with that predicate, and every
+    launcher of a GTE_HOT_ONLY translation unit must refuse a launch it does not cover — so a
+    launch predicate cannot drift from a compiled-out feature again (round 2: `final_info` read
+    records the kernel never wrote)."""
+    csrc = os.path.join(ROOT, "gym-trading-env_amd", "csrc")
+    read = lambda f: open(os.path.join(csrc, f)).read()
+    dev = read("gte_device.h")
+    body = re.search(r"inline bool hot_tu_covers\(const Params& p\) \{(.*?)\}", dev, re.S).group(1)
+    kernels = read("gte_kernels.hip")
+    # blocks inside device code carry `// p.<field>:`; the two file-scope blocks (host launchers,
+    # helper kernels of the shared TU) do not touch phase A
+    blocks = re.findall(r"#ifndef GTE_HOT_ONLY(.*)", kernels)
+    fields = [re.match(r"\s*//\s*p\.([a-z_]+)", b) for b in blocks]
+    named = [m.group(1) for m in fields if m]
+    assert len(blocks) - len(named) == 2, "an #ifndef GTE_HOT_ONLY block inside phase A does not name its field"
+    assert sorted(named) == ["final_rec", "log"]
+    for f in named:
+        assert re.search(rf"p\.{f}\b", body), f"hot_tu_covers does not test p.{f}"
+    api = read("gte_api.hip")
+    assert re.search(r"const bool hot = [^;]*gte::hot_tu_covers\(p\)", api)
+    for tu in ("gte_hot.hip", "gte_rollout.hip"):
+        src = read(tu)
+        assert "#define GTE_HOT_ONLY 1" in src
+        launchers = re.findall(r"hipError_t (?:GTE_HOT_NAME\()?(launch_[a-z_]+)\)?\(const Params& p.*?\n\}", src, re.S)
+        assert launchers
+        for m in re.finditer(r"hipError_t (?:GTE_HOT_NAME\()?launch_[a-z_]+\)?\(const Params& p.*?\n\}", src, re.S):
+            assert "if (!hot_tu_covers(p)) return hipErrorInvalidValue;" in m.group(0), m.group(0)[:80]
+
+
 def test_integration_md_stub_matches_the_abi():
     """The ctypes stub INTEGRATION.md shows a maintainer of the reference is not prose: its
     gte_config must have the fields, order and size of the real one."""
