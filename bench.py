@@ -385,6 +385,10 @@ def main():
     ap.add_argument("--gather-depth", type=int, default=2,
                     help="block mode: blocks in rotation (a block's all-gather overlaps the steps "
                          "that fill the next one on RCCL's stream)")
+    ap.add_argument("--graph-steps", type=int, default=0, metavar="G",
+                    help="single GPU: capture G (even) consecutive steps into ONE HIP graph "
+                         "(BatchedTradingEnv.capture_steps) and time replays of it — one host call "
+                         "per G steps — instead of G launches; for launch-bound batches (c2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-python-loop", type=float, default=0.0, metavar="SECONDS",
                     help="cpu_baseline calibration only, no GPU: time the interpreter-bound per-env loop "
@@ -543,12 +547,21 @@ def main():
             one_step(first_step + i)
         drain()
         torch.cuda.synchronize(dev)
+        graph, G = None, args.graph_steps
+        if G and mode is None:  # recorded here, right before the timed region (nothing executes)
+            base = first_step + args.warmup
+            graph = env.capture_steps(lambda i: env.step(actions[(base + i) % n_rows]), G)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         env.timer_start()  # HIP events on the stream the kernel is launched on
-        for i in range(args.steps):
+        done = 0
+        if graph is not None:
+            for _ in range(args.steps // G):
+                graph.replay()
+            done = args.steps // G * G
+        for i in range(done, args.steps):
             one_step(first_step + args.warmup + i)
         drain()  # every all-gather belongs to the timed region
         env.timer_mark()  # end event recorded behind the last launch; read after the wall clock
@@ -646,6 +659,10 @@ def main():
                                          "staggered by an untimed prologue: ~N/%d episode ends and "
                                          "auto-resets in every step" % cycle),
                        "launch": info, "episodes_finished": episodes,
+                       "submission": (f"HIP graph: {args.graph_steps} consecutive steps captured once "
+                                      f"(hipStreamBeginCapture through torch.cuda.graph), one replay per "
+                                      f"{args.graph_steps} steps" if args.graph_steps and mode is None
+                                      else "one gte_step call (one launch) per step"),
                        "datasets": ("one dataset, replicated on every rank" if D == 1 else
                                     f"{world * D} symbols partitioned by rank: rank r keeps symbols "
                                     f"{D}r .. {D}r+{D - 1} resident and its {N} envs only ever visit those "

@@ -923,6 +923,14 @@ class BatchedTradingEnv(_VectorEnvBase):
             _abi.check(self._lib, self._lib.gte_step(self._h, a.ctypes.data, 0))
         self._epoch += 1
 
+    def capture_steps(self, body, n_steps: int):
+        """Record `body(i)` for i in range(n_steps) — each call taking ONE `step()` with a CUDA
+        int32 action tensor, plus any torch code around it (the policy) — into a HIP graph
+        (`torch.cuda.graph`); `.replay()` on the returned `StepGraph` runs them again with one
+        host call.  For launch-bound batches (config 2: 4 096 envs).  n_steps must be even."""
+        from .step_graph import StepGraph
+        return StepGraph(self, body, n_steps)
+
     def read_envs(self, first: int = 0, count=None, with_obs: bool = True, view: bool = False):
         """(snapshots, obs): a structured array [count] with the fields of struct
         gte_env_snapshot (state, reward f64, terminated, truncated) and the observations

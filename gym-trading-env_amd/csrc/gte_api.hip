@@ -712,6 +712,23 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
   if (!E) return fail(GTE_ERR_INVALID, "env is NULL");
   if (!E->was_reset) return fail(GTE_ERR_STATE, "gte_step before gte_reset");
   if (!actions) return fail(GTE_ERR_INVALID, "actions is NULL");
+  // Stream capture (hipStreamBeginCapture by whoever owns the stream — e.g. torch.cuda.graph around
+  // policy + step): everything a step enqueues is capturable — kernels and one memset of the
+  // re-sort — provided nothing comes from pageable host memory, and the host-side bookkeeping a
+  // replay cannot repeat stays consistent: the two-slot terminal counter alternates per launch, so
+  // a graph must hold an EVEN number of steps and be replayed from the slot it was captured at
+  // (gte_get_outputs().term_slot; StepGraph in step_graph.py checks both); the trajectory log's
+  // row index is host state, so logged envs cannot be captured.
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(E->stream, &capture) != hipSuccess) { (void)hipGetLastError(); capture = hipStreamCaptureStatusNone; }
+  if (capture == hipStreamCaptureStatusActive) {
+    if (!actions_on_device)
+      return fail(GTE_ERR_STATE, "gte_step on a capturing stream needs device-resident actions "
+                                 "(a copy from pageable host memory cannot be captured)");
+    if (E->cfg.log_steps > 0)
+      return fail(GTE_ERR_STATE, "gte_step on a capturing stream: the trajectory log's row index is "
+                                 "host state a replay would not advance (log_steps must be 0)");
+  }
   if (E->affinity_period > 0 && ++E->steps_since_rebuild >= E->affinity_period) {
     // envs drift one row per step and ~1/duration of them jump at a reset: re-sort now and
     // then (4 tiny launches, stream-ordered between two steps)

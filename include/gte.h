@@ -223,7 +223,12 @@ int gte_set_autoreset_injection(gte_env* env, int32_t n_episodes,
  * (portfolio.py:44-46) -> valorisation (portfolio.py:7-13) -> done/truncated
  * (:244-251) -> reward (:17-18,:265-267) -> _get_obs (:152-160).
  * actions: i32 [N] position indices, -1 = None (hold, :234); a host pointer,
- * or a device pointer when actions_on_device != 0. */
+ * or a device pointer when actions_on_device != 0.
+ * Stream capture: with device-resident actions and log_steps == 0 everything the call enqueues
+ * can be captured into a HIP graph by the owner of the env's stream (gte_set_stream).  The
+ * terminal counter alternates between its two slots per launch: capture an EVEN number of steps
+ * and replay the graph only when gte_get_outputs().term_slot equals its value at capture time
+ * (it does after any number of replays and after an even number of eager steps). */
 int gte_step(gte_env* env, const int32_t* actions, int32_t actions_on_device);
 
 /* TradingEnv.add_limit_order (environments.py:227-231) for every env with
