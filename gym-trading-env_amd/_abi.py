@@ -154,6 +154,17 @@ class GteLogView(C.Structure):
                 ("interest_fiat", C.c_void_p)]
 
 
+class GteLogBatch(C.Structure):
+    """struct gte_log_batch: host pointers into the library's pinned buffer (gte_read_log_envs)."""
+
+    _fields_ = [("n_ids", C.c_int32), ("max_rows", C.c_int32), ("n_rows", C.c_void_p),
+                ("idx", C.c_void_p), ("step", C.c_void_p), ("position_index", C.c_void_p),
+                ("dataset_index", C.c_void_p), ("portfolio_valuation", C.c_void_p),
+                ("real_position", C.c_void_p), ("reward", C.c_void_p), ("asset", C.c_void_p),
+                ("fiat", C.c_void_p), ("interest_asset", C.c_void_p), ("interest_fiat", C.c_void_p),
+                ("flags", C.c_void_p)]
+
+
 #: dtype of every log array
 LOG_DTYPES = {"idx": "int32", "step": "int32", "position_index": "int32", "dataset_index": "int32",
               "portfolio_valuation": "float64", "real_position": "float64", "reward": "float64",
@@ -184,6 +195,8 @@ SYMBOLS = {
     "gte_get_log": (C.c_int, [C.c_void_p, _P(GteLogView)]),
     "gte_read_log_portfolio": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 4
                                + [_P(C.c_int32)]),
+    "gte_read_log_envs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                    _P(GteLogBatch)]),
     "gte_set_log_reward": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gte_apply_reward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "gte_get_final_state": (C.c_int, [C.c_void_p, _P(GteStateView)]),

@@ -52,12 +52,22 @@ struct StateSoA {
 };
 hipError_t launch_extract_state(const EnvRec* rec, int n, const StateSoA& o, hipStream_t stream);
 hipError_t launch_rewind_queue(EnvRec* rec, int n, hipStream_t stream);
+hipError_t launch_forget_prices(EnvRec* rec, int n, hipStream_t stream);
 hipError_t launch_log(const EnvRec* rec, const double* reward64, const uint8_t* term,
                       const uint8_t* trunc, int n, int64_t row_base, const LogArrays& o,
                       hipStream_t stream);
 hipError_t launch_snapshot(const EnvRec* rec, const double* reward64, const uint8_t* term,
                            const uint8_t* trunc, const float* obs, int64_t obs_elems, int first,
                            int count, void* dst, float* dst_obs, hipStream_t stream);
+struct LogPack {
+  int32_t* n_rows;
+  int32_t *idx, *step, *pos, *dsi;
+  double *pv, *realpos, *reward, *asset, *fiat, *ia, *ifi;
+  uint8_t* flags;
+};
+hipError_t launch_pack_log(const LogArrays& log, int N, int L, long long rows_written, const int32_t* ids,
+                           int n_ids, int max_rows, int finished, const EnvRec* final_rec,
+                           const double* reward64, const LogPack& o, hipStream_t stream);
 const char* rccl_load();
 const char* rccl_error(int code);
 int rccl_unique_id(uint8_t* out128);
@@ -151,6 +161,8 @@ struct gte_env {
   void* h_snap = nullptr;  // pinned host memory for gte_read_envs: snapshots, then observations
   size_t h_snap_bytes = 0;
   bool view_reads = false; // gte_read_envs_view has been used: the buffer is kept at full size
+  void* h_logpack = nullptr;  // pinned host memory for gte_read_log_envs
+  size_t h_logpack_bytes = 0;
 };
 
 template <typename T>
@@ -553,6 +565,13 @@ int gte_upload_dataset(gte_env* E, int32_t d, const float* feat, const double* c
   for (int k = 0; k < 4; ++k) {
     if (E->ds_allocs[k][d]) (void)hipFree(E->ds_allocs[k][d]);
     E->ds_allocs[k][d] = dev[k];
+  }
+  E->p.ds0 = E->h_ds[0];  // the kernels' by-value copy of descriptor 0 (used when D == 1)
+  if (E->was_reset) {
+    // running envs keep the two prices of their next step in their records (EnvRec.px_*): values
+    // of the table that has just been replaced.  Forget them; the next step reads the new table.
+    HIPCHK(gte::launch_forget_prices(E->p.rec, p.N, E->stream));
+    HIPCHK(hipStreamSynchronize(E->stream));
   }
   return GTE_OK;
 }
@@ -1064,6 +1083,53 @@ int gte_read_log_portfolio(gte_env* E, int32_t env_id, int32_t n, double* asset,
   return GTE_OK;
 }
 
+int gte_read_log_envs(gte_env* E, const int32_t* env_ids, int32_t n_ids, int32_t max_rows,
+                      int32_t finished, gte_log_batch* out) {
+  if (!E || !env_ids || !out) return fail(GTE_ERR_INVALID, "NULL argument");
+  if (E->cfg.log_steps <= 0) return fail(GTE_ERR_STATE, "created with log_steps = 0");
+  if (n_ids < 0) return fail(GTE_ERR_INVALID, "n_ids must be >= 0");
+  if (finished && !E->p.final_rec)
+    return fail(GTE_ERR_STATE, "finished episodes need autoreset = same-step with final_obs");
+  const int N = E->p.N, L = E->cfg.log_steps;
+  if (max_rows <= 0 || max_rows > L) max_rows = L;
+  for (int32_t i = 0; i < n_ids; ++i)
+    if (env_ids[i] < 0 || env_ids[i] >= N) return fail(GTE_ERR_INVALID, "env_ids[%d] = %d out of range", i, env_ids[i]);
+  memset(out, 0, sizeof *out);
+  out->n_ids = n_ids; out->max_rows = max_rows;
+  if (n_ids == 0) return GTE_OK;
+  HIPCHK(hipSetDevice(E->cfg.device));
+  // [ids i32 n | n_rows i32 n | pad -> 16] [7 f64 columns] [4 i32 columns] [u8 column]
+  const size_t cells = (size_t)n_ids * (size_t)max_rows;
+  const size_t head = (((size_t)n_ids * 8) + 15) & ~(size_t)15;
+  const size_t need = head + cells * (7 * 8 + 4 * 4 + 1);
+  if (need > E->h_logpack_bytes) {  // pinned and mapped: the kernel writes host memory directly
+    if (E->h_logpack) HIPCHK(hipHostFree(E->h_logpack));
+    E->h_logpack = nullptr; E->h_logpack_bytes = 0;
+    HIPCHK(hipHostMalloc(&E->h_logpack, need + need / 2, hipHostMallocMapped));
+    E->h_logpack_bytes = need + need / 2;
+  }
+  char* b = (char*)E->h_logpack;
+  int32_t* ids = (int32_t*)b;
+  memcpy(ids, env_ids, sizeof(int32_t) * (size_t)n_ids);
+  gte::LogPack o;
+  o.n_rows = ids + n_ids;
+  double* f = (double*)(b + head);
+  o.pv = f; o.realpos = f + cells; o.reward = f + 2 * cells; o.asset = f + 3 * cells;
+  o.fiat = f + 4 * cells; o.ia = f + 5 * cells; o.ifi = f + 6 * cells;
+  int32_t* w = (int32_t*)(f + 7 * cells);
+  o.idx = w; o.step = w + cells; o.pos = w + 2 * cells; o.dsi = w + 3 * cells;
+  o.flags = (uint8_t*)(w + 4 * cells);
+  HIPCHK(gte::launch_pack_log(E->log, N, L, (long long)E->log_rows, ids, n_ids, max_rows, finished ? 1 : 0,
+                              E->p.final_rec, E->p.reward64, o, E->stream));
+  HIPCHK(hipStreamSynchronize(E->stream));
+  out->n_rows = o.n_rows;
+  out->idx = o.idx; out->step = o.step; out->position_index = o.pos; out->dataset_index = o.dsi;
+  out->portfolio_valuation = o.pv; out->real_position = o.realpos; out->reward = o.reward;
+  out->asset = o.asset; out->fiat = o.fiat; out->interest_asset = o.ia; out->interest_fiat = o.ifi;
+  out->flags = o.flags;
+  return GTE_OK;
+}
+
 int gte_set_log_reward(gte_env* E, const double* reward_device) {
   if (!E || !reward_device) return fail(GTE_ERR_INVALID, "NULL argument");
   if (E->cfg.log_steps <= 0) return fail(GTE_ERR_STATE, "created with log_steps = 0");
@@ -1442,6 +1508,7 @@ void gte_destroy(gte_env* E) {
   for (int32_t* q : {E->d_q_idx, E->d_q_pos, E->d_q_ds})
     if (q) (void)hipFree(q);
   if (E->h_snap) (void)hipHostFree(E->h_snap);
+  if (E->h_logpack) (void)hipHostFree(E->h_logpack);
   if (E->ev0) (void)hipEventDestroy(E->ev0);
   if (E->ev1) (void)hipEventDestroy(E->ev1);
   if (E->own_stream) (void)hipStreamDestroy(E->own_stream);

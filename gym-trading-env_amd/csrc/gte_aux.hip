@@ -121,6 +121,75 @@ hipError_t launch_apply_reward(const Params& p, const double* reward, const int3
 }
 
 // ---------------------------------------------------------------------------
+// The logged EPISODE of each of a list of envs, packed into (pinned, device-visible) host memory
+// by one launch: what History holds for them (environments.py:253-264), without one strided copy
+// per column and env.  One workgroup per listed env.  The episode = the last run of logged rows
+// whose `step` counts ..., s-2, s-1, s (the newest row's step s says how far back it can reach;
+// the run is cut where the count breaks, e.g. at the repeated rows of a frozen env, and at the
+// front when it is longer than the log or than max_rows).  finished (same-step auto-reset with
+// final_obs, right after the step in which the env ended): the newest log row already describes
+// the next episode's reset row; the episode that just FINISHED is the rows before it plus the
+// terminal row from the env's terminal record, with that step's reward.
+struct LogPack {
+  int32_t* n_rows;                 // [n_ids]
+  int32_t *idx, *step, *pos, *dsi; // [n_ids, max_rows], rows 0 .. n_rows-1 valid, oldest first
+  double *pv, *realpos, *reward, *asset, *fiat, *ia, *ifi;
+  uint8_t* flags;
+};
+
+__global__ __launch_bounds__(256) void gte_pack_log_kernel(const LogArrays log, int N, int L,
+                                                           long long rows_written, const int32_t* ids,
+                                                           int max_rows, int finished,
+                                                           const EnvRec* final_rec, const double* reward64,
+                                                           LogPack o) {
+  __shared__ int s_start;
+  const int j = blockIdx.x, tid = threadIdx.x;
+  const int e = ids[j];
+  const int have = (int)(rows_written < (long long)L ? rows_written : (long long)L);
+  if (have <= 0) { if (tid == 0) o.n_rows[j] = 0; return; }
+  // logical row r = 0 .. have-1 (oldest first) lives at physical row (rows_written - have + r) % L
+  const long long base = rows_written - have;
+  auto at = [&](int r) -> int64_t { return (int64_t)((base + r) % L) * N + e; };
+  const bool fin = finished != 0;
+  auto step_at = [&](int r) -> int32_t { return (fin && r == have - 1) ? final_rec[e].step : log.step[at(r)]; };
+  const int32_t s_new = step_at(have - 1);
+  int r0 = have - 1 - s_new;
+  if (r0 < 0) r0 = 0;
+  if (tid == 0) s_start = r0;
+  __syncthreads();
+  for (int r = r0 + 1 + tid; r < have; r += blockDim.x)
+    if (step_at(r - 1) != step_at(r) - 1) atomicMax(&s_start, r);
+  __syncthreads();
+  int start = s_start;
+  int n = have - start;
+  if (n > max_rows) { start = have - max_rows; n = max_rows; }
+  if (tid == 0) o.n_rows[j] = n;
+  for (int r = tid; r < n; r += blockDim.x) {
+    const int rr = start + r;
+    const int64_t k = at(rr), d = (int64_t)j * max_rows + r;
+    if (fin && rr == have - 1) {
+      const EnvRec t = final_rec[e];
+      o.idx[d] = t.idx; o.step[d] = t.step; o.pos[d] = t.pos; o.dsi[d] = t.dsi;
+      o.pv[d] = t.pv; o.realpos[d] = t.realpos; o.reward[d] = reward64[e];
+      o.asset[d] = t.asset; o.fiat[d] = t.fiat; o.ia[d] = t.ia; o.ifi[d] = t.ifi;
+    } else {
+      o.idx[d] = log.idx[k]; o.step[d] = log.step[k]; o.pos[d] = log.pos[k]; o.dsi[d] = log.dsi[k];
+      o.pv[d] = log.pv[k]; o.realpos[d] = log.realpos[k]; o.reward[d] = log.reward[k];
+      o.asset[d] = log.asset[k]; o.fiat[d] = log.fiat[k]; o.ia[d] = log.ia[k]; o.ifi[d] = log.ifi[k];
+    }
+    o.flags[d] = log.flags[k];
+  }
+}
+
+hipError_t launch_pack_log(const LogArrays& log, int N, int L, long long rows_written, const int32_t* ids,
+                           int n_ids, int max_rows, int finished, const EnvRec* final_rec,
+                           const double* reward64, const LogPack& o, hipStream_t stream) {
+  hipLaunchKernelGGL(gte_pack_log_kernel, dim3(n_ids), dim3(256), 0, stream, log, N, L, rows_written, ids,
+                     max_rows, finished, final_rec, reward64, o);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // State, returns and observation of a range of envs, packed into (pinned, device-visible)
 // host memory: `count` gte_env_snapshot structs, then `count` observations.
 struct SnapshotPacked {

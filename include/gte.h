@@ -284,6 +284,35 @@ int gte_read_log(gte_env* env, int32_t env_id, int32_t n, int32_t* idx, int32_t*
 /* the Portfolio columns of the same rows (asset, fiat, interest_asset, interest_fiat) */
 int gte_read_log_portfolio(gte_env* env, int32_t env_id, int32_t n, double* asset, double* fiat,
                            double* interest_asset, double* interest_fiat, int32_t* n_out);
+/* The logged EPISODE of each of n_ids envs (HOST array env_ids) in ONE transfer: one kernel packs
+ * them into pinned host memory, one stream synchronisation — what History holds for those envs
+ * (environments.py:253-264; the reference's add_metric / get_metrics functions and save_for_render
+ * read it, :274-307).  Episode of an env = the last run of its logged rows whose `step` counts up
+ * by one to the newest row (cut at the front when longer than the log or than max_rows; max_rows
+ * <= 0 means L).  finished != 0 (same-step auto-reset with final_obs, right after the step in
+ * which the envs ended): the episode that just FINISHED — the rows before the newest one (which
+ * already is the next episode's reset row) plus the terminal row from the env's terminal record
+ * with that step's reward.  The arrays are [n_ids, max_rows] row-major, rows 0 .. n_rows[j]-1 of
+ * env j valid, oldest first; they live in library-owned host memory and stay valid until the next
+ * gte_read_log_envs / gte_destroy. */
+typedef struct gte_log_batch {
+  int32_t n_ids, max_rows;
+  const int32_t* n_rows;            /* i32 [n_ids] */
+  const int32_t* idx;               /* i32 [n_ids, max_rows] */
+  const int32_t* step;
+  const int32_t* position_index;
+  const int32_t* dataset_index;
+  const double*  portfolio_valuation; /* f64 [n_ids, max_rows] */
+  const double*  real_position;
+  const double*  reward;
+  const double*  asset;
+  const double*  fiat;
+  const double*  interest_asset;
+  const double*  interest_fiat;
+  const uint8_t* flags;             /* u8 [n_ids, max_rows] bit0 terminated, bit1 truncated */
+} gte_log_batch;
+int gte_read_log_envs(gte_env* env, const int32_t* env_ids, int32_t n_ids, int32_t max_rows,
+                      int32_t finished, gte_log_batch* out);
 /* Overwrite the `reward` column of the NEWEST log row with device values f64 [N] — what the
  * reference does with a custom reward_function: `historical_info["reward", -1] = reward`
  * (environments.py:265-267).  Stream-ordered. */
