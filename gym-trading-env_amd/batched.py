@@ -684,6 +684,93 @@ class BatchedTradingEnv(_VectorEnvBase):
             raise ValueError("add_metric needs log_steps > 0 (the History comes from the device log)")
         self.log_metrics.append({"name": name, "function": function})
 
+    def read_log_envs(self, env_ids, finished: bool = False, max_rows=None) -> dict:
+        """The logged episode of each listed env in ONE device->host transfer
+        (`gte_read_log_envs`): dict of arrays [n_ids, max_rows] — the log columns of
+        `_abi.LOG_DTYPES` — plus "n_rows" [n_ids]; rows 0 .. n_rows[j]-1 of env j are valid,
+        oldest first.  Views of the library's pinned staging buffer: valid until the next call.
+        finished=True: the episodes that just ENDED (same-step auto-reset with ``final_obs``)."""
+        L = int(self.cfg.log_steps)
+        if not L:
+            raise ValueError("constructed with log_steps=0")
+        ids = np.ascontiguousarray(np.asarray(env_ids, dtype=np.int32).reshape(-1))
+        b = _abi.GteLogBatch()
+        _abi.check(self._lib, self._lib.gte_read_log_envs(
+            self._h, ids.ctypes.data, len(ids), int(max_rows or 0), 1 if finished else 0, C.byref(b)))
+        n, R = int(b.n_ids), int(b.max_rows)
+        out = {"n_rows": np.zeros(0, np.int32)}
+        if n:
+            out["n_rows"] = np.frombuffer((C.c_int32 * n).from_address(b.n_rows), dtype=np.int32)
+        for name, dt in _abi.LOG_DTYPES.items():
+            dt = np.dtype(dt)
+            if not n:
+                out[name] = np.zeros((0, R), dt)
+                continue
+            raw = (C.c_char * (n * R * dt.itemsize)).from_address(getattr(b, name))
+            out[name] = np.frombuffer(raw, dtype=dt).reshape(n, R)
+        return out
+
+    def histories(self, env_ids, finished: bool = False) -> list:
+        """One `History` per listed env: its current (or, finished=True, just finished) episode
+        with the reference's columns (environments.py:186-197, 253-264), rebuilt from the device
+        trajectory log.  ONE transfer for all of them; the columns are built once over the
+        concatenated rows and cut per env."""
+        from .history import ColumnBlock, History
+        ids = np.asarray(env_ids, dtype=np.int64).reshape(-1)
+        if finished and not self.cfg.final_obs:
+            raise ValueError("history(finished=True) needs autoreset='same_step', final_obs=True")
+        b = self.read_log_envs(ids, finished=finished)
+        n = b["n_rows"].astype(np.int64)
+        if finished and len(ids):
+            last = b["flags"][np.arange(len(ids)), np.maximum(n - 1, 0)]
+            bad = np.nonzero((n == 0) | ((last & 3) == 0))[0]
+            if len(bad):
+                raise ValueError(f"env {int(ids[bad[0]])} did not end in the last step")
+        R = b["idx"].shape[1]
+        valid = np.arange(R)[None, :] < n[:, None]
+        raw = {}
+
+        def flat(name):  # the valid rows of every env, env after env (copied out of the staging buffer)
+            v = raw.get(name)
+            if v is None:
+                v = raw[name] = b[name][valid]
+            return v
+        for name in ("dataset_index", "idx"):  # the lookups below outlive the staging buffer
+            flat(name)
+        pos_table = np.empty(len(self.positions), dtype=object)
+        pos_table[:] = self.positions
+        dist = lambda src, sign: (lambda: np.maximum(0, sign * flat(src)))
+        # Every column is built on first use, over all the episodes at once, and cut per env: a
+        # metric that reads `h["position"]` never pays for dates or portfolio distributions.
+        builders = {"idx": lambda: flat("idx"), "step": lambda: flat("step"),
+                    "date": lambda: self._dataset_column("date", flat("dataset_index"), flat("idx")),
+                    "position_index": lambda: flat("position_index"),
+                    "position": lambda: pos_table[flat("position_index")],
+                    "real_position": lambda: flat("real_position")}
+        for c in self.datasets[0].info_columns or ["close"]:
+            builders[f"data_{c}"] = (lambda c=c: self._dataset_column(
+                f"data_{c}", flat("dataset_index"), flat("idx")))
+        builders["portfolio_valuation"] = lambda: flat("portfolio_valuation")
+        # Portfolio.get_portfolio_distribution, portfolio.py:49-57
+        builders["portfolio_distribution_asset"] = dist("asset", 1.0)
+        builders["portfolio_distribution_fiat"] = dist("fiat", 1.0)
+        builders["portfolio_distribution_borrowed_asset"] = dist("asset", -1.0)
+        builders["portfolio_distribution_borrowed_fiat"] = dist("fiat", -1.0)
+        builders["portfolio_distribution_interest_asset"] = lambda: flat("interest_asset")
+        builders["portfolio_distribution_interest_fiat"] = lambda: flat("interest_fiat")
+        builders["reward"] = lambda: flat("reward")
+        # the staging buffer is rewritten by the next read: take the raw columns out of it now (one
+        # boolean-mask copy each, 12 small arrays), the derived columns stay lazy
+        for name in _abi.LOG_DTYPES:
+            flat(name)
+        block = ColumnBlock(builders)
+        ends = np.cumsum(n).tolist()
+        out, lo = [], 0
+        for hi in ends:
+            out.append(History.from_block(block, lo, hi))
+            lo = hi
+        return out
+
     def history(self, env_id: int, finished: bool = False):
         """The current (or just finished) episode of one env as a `History` with the
         reference's columns (environments.py:186-197, 253-264: idx, step, date, position_index,
@@ -693,64 +780,9 @@ class BatchedTradingEnv(_VectorEnvBase):
 
         finished=True (same-step auto-reset with ``final_obs``, right after the step in which the
         env ended): the episode that just FINISHED — its rows from the log plus the terminal row
-        from the env's terminal record (that step's log row already describes the new episode)."""
-        from .history import History
-        L = int(self.cfg.log_steps)
-        if not L:
-            raise ValueError("constructed with log_steps=0")
-        bufs = {"idx": np.empty(L, np.int32), "step": np.empty(L, np.int32),
-                "pos": np.empty(L, np.int32), "ds": np.empty(L, np.int32),
-                "pv": np.empty(L, np.float64), "rp": np.empty(L, np.float64),
-                "rew": np.empty(L, np.float64), "flags": np.empty(L, np.uint8)}
-        port = {k: np.empty(L, np.float64) for k in ("asset", "fiat", "ia", "ifi")}
-        n = C.c_int32()
-        _abi.check(self._lib, self._lib.gte_read_log(
-            self._h, int(env_id), L, *(b.ctypes.data for b in bufs.values()), C.byref(n)))
-        _abi.check(self._lib, self._lib.gte_read_log_portfolio(
-            self._h, int(env_id), L, *(b.ctypes.data for b in port.values()), C.byref(n)))
-        n = n.value
-        if finished:
-            if not self.cfg.final_obs:
-                raise ValueError("history(finished=True) needs autoreset='same_step', final_obs=True")
-            if not (bufs["flags"][n - 1] & 3):
-                raise ValueError(f"env {env_id} did not end in the last step")
-            # drop the newest row (the reset row of the next episode) and put the terminal row,
-            # with that step's reward, in its place
-            e = int(env_id)
-            fs = self.final_state
-            for key, name in (("idx", "idx"), ("step", "step"), ("pos", "position_index"),
-                              ("ds", "dataset_index"), ("pv", "portfolio_valuation"),
-                              ("rp", "real_position")):
-                bufs[key][n - 1] = fs(name)[e]
-            for key, name in (("asset", "asset"), ("fiat", "fiat"), ("ia", "interest_asset"),
-                              ("ifi", "interest_fiat")):
-                port[key][n - 1] = fs(name)[e]
-            bufs["rew"][n - 1] = self.read_output("reward64")[e]  # (the reset row under it logs 0)
-        step = bufs["step"][:n]
-        # the episode = the last run of rows whose step counts 0, 1, 2, ...
-        start = n - 1
-        while start > 0 and step[start - 1] == step[start] - 1:
-            start -= 1
-        sl = slice(start, n)
-        ds, idx, pos = bufs["ds"][sl], bufs["idx"][sl], bufs["pos"][sl]
-        asset, fiat = port["asset"][sl], port["fiat"][sl]
-        cols = {"idx": idx.tolist(), "step": step[sl].tolist(),
-                "date": list(self._dataset_column("date", ds, idx)),
-                "position_index": pos.tolist(),
-                "position": [self.positions[i] for i in pos],
-                "real_position": bufs["rp"][sl].tolist()}
-        for c in self.datasets[0].info_columns or ["close"]:
-            cols[f"data_{c}"] = list(self._dataset_column(f"data_{c}", ds, idx))
-        cols["portfolio_valuation"] = bufs["pv"][sl].tolist()
-        # Portfolio.get_portfolio_distribution, portfolio.py:49-57
-        cols["portfolio_distribution_asset"] = np.maximum(0, asset).tolist()
-        cols["portfolio_distribution_fiat"] = np.maximum(0, fiat).tolist()
-        cols["portfolio_distribution_borrowed_asset"] = np.maximum(0, -asset).tolist()
-        cols["portfolio_distribution_borrowed_fiat"] = np.maximum(0, -fiat).tolist()
-        cols["portfolio_distribution_interest_asset"] = port["ia"][sl].tolist()
-        cols["portfolio_distribution_interest_fiat"] = port["ifi"][sl].tolist()
-        cols["reward"] = bufs["rew"][sl].tolist()
-        return History.from_columns(cols)
+        from the env's terminal record (that step's log row already describes the new episode).
+        For many envs use :meth:`histories` (one transfer for all of them)."""
+        return self.histories([int(env_id)], finished=finished)[0]
 
     def save_for_render(self, env_id: int, dir="render_logs"):
         """`TradingEnv.save_for_render` (environments.py:296-307) for one env of the batch: the
@@ -795,7 +827,7 @@ class BatchedTradingEnv(_VectorEnvBase):
                "Market Return": [f"{100 * m:5.2f}%" for m in market.tolist()],
                "Portfolio Return": [f"{100 * r:5.2f}%" for r in portfolio.tolist()]}
         if self.log_metrics:  # custom metrics over each finished env's History (:285-286)
-            hists = [self.history(int(e), finished=use_final) for e in ids]
+            hists = self.histories(ids, finished=use_final)  # ONE transfer for all of them
             for metric in self.log_metrics:
                 out[metric["name"]] = [metric["function"](h) for h in hists]
         return out

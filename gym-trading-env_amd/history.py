@@ -30,12 +30,42 @@ def _flatten(kwargs):
     return names, values
 
 
+class ColumnBlock:
+    """The History columns of MANY episodes laid end to end, each built on first use: what the
+    batch makes out of one `gte_read_log_envs` transfer.  `History.from_block(block, lo, hi)` is
+    the episode in rows lo .. hi-1; a column nobody asks for is never built, and no Python object
+    is made per logged value until one is read."""
+
+    def __init__(self, builders: dict):
+        self.names = list(builders)
+        self._builders = builders
+        self._built = {}
+
+    def get(self, name):
+        v = self._built.get(name)
+        if v is None:
+            v = self._built[name] = np.asarray(self._builders[name]())
+        return v
+
+
 class History:
     def __init__(self, max_size=10000):
         self.height = max_size
         self.columns = []
         self._cols = {}
+        self._block = None
         self.size = 0
+
+    @classmethod
+    def from_block(cls, block: ColumnBlock, lo: int, hi: int):
+        """Rows lo .. hi-1 of a ColumnBlock as one episode's History (columns cut out on first
+        access)."""
+        h = cls(max_size=max(1, hi - lo))
+        h.columns = list(block.names)
+        h.width = len(h.columns)
+        h._block = (block, int(lo), int(hi))
+        h.size = int(hi - lo)
+        return h
 
     @classmethod
     def from_columns(cls, columns: dict):
@@ -62,7 +92,17 @@ class History:
                              f"Initial ones : {self.columns}. New ones {names}")
         self._append(values)
 
+    def _own_lists(self):
+        """Before anything is written: every column as this History's own Python list."""
+        for c in self.columns:
+            v = self._col(c)
+            if not isinstance(v, list):
+                self._cols[c] = v.tolist() if v.dtype.kind != "M" else list(v)
+        self._block = None
+
     def _append(self, values):
+        if self._block is not None:
+            self._own_lists()
         if self.size >= self.height:  # the reference indexes row `size` of a `height`-row array
             raise IndexError(f"index {self.size} is out of bounds for axis 0 with size {self.height}")
         for c, v in zip(self.columns, values):
@@ -76,31 +116,45 @@ class History:
         try:
             return self._cols[name]
         except KeyError:
+            if self._block is not None and name in self._block[0]._builders:
+                block, lo, hi = self._block
+                v = self._cols[name] = block.get(name)[lo:hi]
+                return v
             raise ValueError(f"Feature {name} does not exist ... Check the available "
                              f"features : {self.columns}") from None
 
     @staticmethod
     def _array(values):
         out = np.empty(len(values), dtype=object)
-        out[:] = values
+        if isinstance(values, np.ndarray):
+            # Python scalars like the lists hold (datetime64 values stay datetime64 scalars)
+            out[:] = list(values) if values.dtype.kind == "M" else values.tolist()
+        else:
+            out[:] = values
         return out
 
     def __getitem__(self, arg):
         if isinstance(arg, tuple):
             column, t = arg
             col = self._col(column)
-            return self._array(col)[t] if isinstance(t, slice) else col[t]
+            if isinstance(t, slice):
+                return self._array(col)[t]
+            v = col[t]
+            # a value cut out of a numeric block column: the Python scalar a list would hold
+            return v.item() if isinstance(v, np.generic) and not isinstance(v, np.datetime64) else v
         if isinstance(arg, (int, np.integer)):
-            return {c: self._cols[c][arg] for c in self.columns}
+            return {c: self[c, arg] for c in self.columns}
         if isinstance(arg, str):
             return self._array(self._col(arg))
         if isinstance(arg, list):
             out = np.empty((self.size, len(arg)), dtype=object)
             for j, c in enumerate(arg):
-                out[:, j] = self._col(c)
+                out[:, j] = self._array(self._col(c))
             return out
         raise TypeError(f"unsupported History index {arg!r}")
 
     def __setitem__(self, arg, value):
         column, t = arg
+        if self._block is not None:
+            self._own_lists()
         self._col(column)[t] = value

@@ -671,3 +671,90 @@ def test_trajectory_row_written_by_the_step_kernel_equals_the_separate_launch(mo
             m = (a._t["terminated"] | a._t["truncated"]).to(torch.uint8).cpu().numpy()
             a.reset(mask=m); b.reset(mask=m)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("mode,L", [("next_step", 32), ("same_step", 32), ("disabled", 32), ("next_step", 5)])
+def test_read_log_envs_equals_the_per_env_reads(mode, L):
+    """`gte_read_log_envs` (one kernel packs the logged episode of MANY envs into pinned host
+    memory, one transfer) against the per-env strided copies of `gte_read_log` /
+    `gte_read_log_portfolio` with the episode cut on the host: every column, every listed env —
+    running, just reset, frozen after its end (auto-reset disabled), episodes longer than the log
+    (L = 5), `finished=True` with the terminal row from the terminal records, `max_rows`."""
+    import ctypes as C
+    from gym_trading_env_amd import _abi
+    from gym_trading_env_amd.batched import BatchedTradingEnv
+    feat, close = _walk(77, 400, 6, sigma=3e-2, drift=-1e-3)
+    N = 700
+    env = BatchedTradingEnv((feat, close), N, positions=[-1, 0, 1], windows=4, trading_fees=1e-3,
+                            borrow_interest_rate=1e-4, max_episode_duration=9, seed=5, autoreset=mode,
+                            final_obs=(mode == "same_step"), log_steps=L, output="numpy")
+    env.reset()
+    rng = np.random.default_rng(2)
+    names = list(_abi.LOG_DTYPES)
+
+    def per_env(e, finished):
+        bufs = {k: np.empty(L, _abi.LOG_DTYPES[k]) for k in names}
+        n = C.c_int32()
+        order = ("idx", "step", "position_index", "dataset_index", "portfolio_valuation", "real_position",
+                 "reward", "flags")
+        _abi.check(env._lib, env._lib.gte_read_log(env._h, int(e), L, *(bufs[k].ctypes.data for k in order), C.byref(n)))
+        _abi.check(env._lib, env._lib.gte_read_log_portfolio(
+            env._h, int(e), L, *(bufs[k].ctypes.data for k in ("asset", "fiat", "interest_asset", "interest_fiat")),
+            C.byref(n)))
+        n = n.value
+        if finished:
+            fs = env.final_state
+            for k in ("idx", "step", "position_index", "dataset_index", "portfolio_valuation", "real_position",
+                      "asset", "fiat", "interest_asset", "interest_fiat"):
+                bufs[k][n - 1] = fs(k)[e]
+            bufs["reward"][n - 1] = env.read_output("reward64")[e]
+        step = bufs["step"][:n]
+        start = n - 1
+        while start > 0 and step[start - 1] == step[start] - 1:
+            start -= 1
+        return {k: bufs[k][start:n] for k in names}
+
+    checked = 0
+    for k in range(24):
+        a = rng.integers(0, 3, N).astype(np.int32)
+        _, _, term, trunc, _ = env.step(a)
+        ended = term | trunc
+        if k % 3 == 2 or k < 3:
+            ids = np.unique(np.concatenate([rng.integers(0, N, 40), np.nonzero(ended)[0][:30], [0, N - 1]]))
+            got = env.read_log_envs(ids)
+            for j, e in enumerate(ids):
+                want = per_env(e, False)
+                n = int(got["n_rows"][j])
+                assert n == len(want["idx"]), (k, e)
+                for name in names:
+                    np.testing.assert_array_equal(got[name][j, :n], want[name], err_msg=f"step {k} env {e} {name}")
+                checked += 1
+            # max_rows keeps the NEWEST rows (the arrays are views of ONE staging buffer: copy first)
+            rows, pv = got["n_rows"].copy(), got["portfolio_valuation"].copy()
+            got3 = env.read_log_envs(ids, max_rows=3)
+            for j in range(len(ids)):
+                n, n3 = int(rows[j]), int(got3["n_rows"][j])
+                assert n3 == min(n, 3)
+                np.testing.assert_array_equal(got3["portfolio_valuation"][j, :n3], pv[j, n - n3:n])
+            if mode == "same_step" and ended.any():
+                fin = np.nonzero(ended)[0]
+                gotf = env.read_log_envs(fin, finished=True)
+                for j, e in enumerate(fin[:50]):
+                    want = per_env(e, True)
+                    n = int(gotf["n_rows"][j])
+                    assert n == len(want["idx"]) and n >= 2
+                    for name in names:
+                        np.testing.assert_array_equal(gotf[name][j, :n], want[name], err_msg=f"finished {e} {name}")
+                # the History objects built from it: the single-env path is the batch of one
+                hs = env.histories(fin[:5], finished=True)
+                for e, h in zip(fin[:5], hs):
+                    h1 = env.history(int(e), finished=True)
+                    assert len(h) == len(h1) and h[-1] == h1[-1] and h[0] == h1[0]
+                    assert h["step", -1] == len(h) - 1 or len(h) == L
+        if mode == "disabled" and k % 5 == 4:
+            env.reset(mask=ended.astype(np.uint8))
+    assert checked > 300
+    assert len(env.histories([])) == 0
+    with pytest.raises(Exception):
+        env.read_log_envs([N])
+    env.close()

@@ -102,3 +102,45 @@ def test_history_answers_like_the_reference():
     with pytest.raises(IndexError):
         full.add(a=3)
     assert fx["answers"]["add() beyond max_size"] == {"raises": "IndexError"}
+
+
+def test_block_backed_history_equals_the_list_backed_one():
+    """`History.from_block` (columns of many episodes built lazily, cut per episode: what the batch
+    makes of one gte_read_log_envs transfer) answers every access pattern like a History filled
+    from Python lists, Python scalars included; writing to it detaches it from the block."""
+    import numpy as np
+    from gym_trading_env_amd.history import ColumnBlock, History
+    rng = np.random.default_rng(0)
+    n = 40
+    pos_table = np.empty(3, dtype=object)
+    pos_table[:] = [-1, 0, 0.5]
+    cols = {"idx": rng.integers(0, 99, n).astype(np.int32), "pv": rng.normal(size=n),
+            "date": np.arange("2022-01-01", n, dtype="datetime64[h]").astype("datetime64[ns]"),
+            "position": pos_table[rng.integers(0, 3, n)], "label": np.array(["a", "b"] * (n // 2), dtype=object)}
+    built = []
+    block = ColumnBlock({k: (lambda k=k: (built.append(k), cols[k])[1]) for k in cols})
+    for lo, hi in ((0, 7), (7, 8), (8, 40)):
+        h = History.from_block(block, lo, hi)
+        ref = History.from_columns({k: (list(v[lo:hi]) if v.dtype.kind == "M" else v[lo:hi].tolist())
+                                    for k, v in cols.items()})
+        assert len(h) == len(ref) == hi - lo and h.columns == ref.columns
+        for c in cols:
+            for t in (0, -1):
+                a, b = h[c, t], ref[c, t]
+                assert a == b and type(a) is type(b), (c, a, b)
+            np.testing.assert_array_equal(h[c], ref[c])
+            assert h[c].dtype == object and type(h[c][0]) is type(ref[c][0])
+            np.testing.assert_array_equal(h[c, 1:3], ref[c, 1:3])
+        assert h[-1] == ref[-1] and h[0] == ref[0]
+        np.testing.assert_array_equal(h[["pv", "date"]], ref[["pv", "date"]])
+        with pytest.raises(ValueError):
+            h["nope", 0]
+    assert sorted(set(built)) == sorted(cols) and len(built) == len(cols)  # each column built once
+    lazy = ColumnBlock({"a": lambda: np.arange(4.0), "b": lambda: 1 / 0})
+    h = History.from_block(lazy, 1, 3)
+    assert h["a", -1] == 2.0  # "b" is never built
+    h2 = History.from_block(ColumnBlock({"a": lambda: np.arange(4.0)}), 1, 3)
+    h2["a", -1] = 9.5
+    assert h2["a", -1] == 9.5 and h2["a", 0] == 1.0
+    with pytest.raises(IndexError):  # full, like the reference's fixed-height array (and from_columns)
+        h2.add(a=7.0)
