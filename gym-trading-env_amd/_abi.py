@@ -236,7 +236,8 @@ SYMBOLS = {
 }
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgte.so")
+# GTE_LIBRARY: another BUILD of libgte to load instead (A/B builds of the kernels, tools/)
+LIB_PATH = os.environ.get("GTE_LIBRARY") or os.path.join(_HERE, "csrc", "libgte.so")
 _lib = None
 
 

@@ -20,6 +20,21 @@
 #define GTE_WAVES 4
 #endif
 
+// Round-3 experiment switches (A/B builds: make EXP="-DGTE_EXP_...=0|1"; tools/lib_ab.py): each
+// moves something off the head of phase A's dependency chain.  The defaults are the product.
+//   GTE_EXP_PRICE_CACHE  the next step's two prices and the dataset's row count travel in EnvRec
+//   GTE_EXP_DS0          descriptor 0 in the kernel arguments (no descriptor load with one dataset)
+//   GTE_EXP_POS_LDS      positions[] looked up in an LDS copy instead of global memory
+#ifndef GTE_EXP_PRICE_CACHE
+#define GTE_EXP_PRICE_CACHE 1
+#endif
+#ifndef GTE_EXP_DS0
+#define GTE_EXP_DS0 1
+#endif
+#ifndef GTE_EXP_POS_LDS
+#define GTE_EXP_POS_LDS 1
+#endif
+
 namespace gte {
 
 struct DatasetDesc {

@@ -68,6 +68,16 @@ enum { MODE_STEP = 0, MODE_RESET = 1 };
 // (episode, eps_on_ds, n_picks, q_head) stay in the record and are read / written there, inside
 // the rare reset branches: carried through the fp64 state machine they cost the step kernel
 // four more VGPRs, i.e. an occupancy step.
+// A pointer that was itself LOADED (a dataset descriptor's members) or that travelled through LDS
+// as an integer (the window's source) is a generic pointer to the compiler: it emits flat_load,
+// and flat loads count on vmcnt AND lgkmcnt — every LDS wait behind one, the workgroup barrier's
+// included, then waits for global memory.  Cast back to the global address space explicitly.
+template <typename T>
+__device__ inline T load_global(uint64_t base, int64_t index) {
+  typedef const T __attribute__((address_space(1))) * gptr_t;
+  return ((gptr_t)base)[index];
+}
+
 struct EnvRegs {
   int32_t idx, step, pos, dsi, start, needs_reset, lo_n, ds_T;
   Portfolio q;
@@ -120,15 +130,19 @@ __device__ inline void store_prices(EnvRec* r, const PriceCarry& c) {
 // loads from its descriptor
 __device__ inline void dataset_pointers(const Params& p, int32_t dsi, const float*& feat,
                                         const double*& close) {
-  if (p.D == 1) { feat = p.ds0.feat; close = p.ds0.close; return; }  // wave-uniform
+  if (GTE_EXP_DS0 && p.D == 1) { feat = p.ds0.feat; close = p.ds0.close; return; }  // wave-uniform
   const DatasetDesc* dp = p.ds + dsi;
   feat = dp->feat; close = dp->close;
 }
 
 // positions[i]: from the workgroup's LDS copy when the caller staged one (no global load behind
-// the record load on the step's dependency chain), else from the table in global memory
-__device__ inline double position_value(const Params& p, const double* pos_lds, int32_t i) {
-  return pos_lds ? pos_lds[i] : p.positions[i];
+// the record load on the step's dependency chain), else from the table in global memory.  The LDS
+// pointer keeps its address space in its TYPE: as a generic pointer the two sources merge into one
+// flat_load (which ties up both vmcnt and lgkmcnt).
+typedef const double __attribute__((address_space(3))) * lds_f64_ptr;
+__device__ inline double position_value(const Params& p, lds_f64_ptr pos_lds, int32_t i) {
+  if (pos_lds) return pos_lds[i];
+  return p.positions[i];
 }
 
 // MultiDatasetTradingEnv.next_dataset, environments.py:380-391
@@ -174,10 +188,10 @@ __device__ inline void do_reset(const Params& p, int e, int32_t inj_idx, int32_t
   s.ds_T = (int32_t)d.T;
   rec->ds_T = s.ds_T;
   const double position = p.positions[pi];  // TargetPortfolio, portfolio.py:59-66
-  const double price = d.close[idx];
+  const double price = load_global<double>((uint64_t)d.close, idx);
   // the first step of the episode trades at this price and values at the next row's (idx <= T - 2:
   // gte_upload_dataset / check_injection)
-  pc.cur = price; pc.next = d.close[idx + 1]; pc.idx = idx; pc.dsi = s.dsi;
+  pc.cur = price; pc.next = load_global<double>((uint64_t)d.close, idx + 1); pc.idx = idx; pc.dsi = s.dsi;
   s.q.asset = position * p.V0 / price;
   s.q.fiat = (1.0 - position) * p.V0;
   s.q.ia = 0.0;
@@ -303,16 +317,15 @@ struct StepOut {
 // steps: no record load per step; the record is still written through); action_in: the action
 // was loaded ahead of time.  Both are nullptr — and fold away — in the per-step kernels.
 // pc: the prices known one step ahead (PriceCarry) — a fused rollout's registers; nullptr: read
-// from / written back to the env's record.  px_out: do not store them, hand them to the caller
-// (the step kernel stores them after its barrier: the value asked for last is then not waited for
-// in front of it).  pos_lds: the workgroup's LDS copy of `positions`, or nullptr.
+// from / written back to the env's record.  pos_lds: the workgroup's LDS copy of `positions`, or
+// nullptr.
 template <int MODE>
 __device__ inline void phase_a(const Params& p, int e, bool active, int lane, ObsJob& job,
                                FinalJob* fin = nullptr, bool compact = true,
                                double* pv_out = nullptr, EnvRegs* carried = nullptr,
                                const int32_t* action_in = nullptr, bool write_record = true,
                                PriceCarry* pc = nullptr, StepOut* so = nullptr,
-                               PriceCarry* px_out = nullptr, const double* pos_lds = nullptr) {
+                               lds_f64_ptr pos_lds = nullptr) {
   // write_record = false (fused rollouts, with `carried`): the record is not written through on
   // this step — the caller stores it once, after its last step (fields a reset or a limit-order
   // fill changes are written where they change, whatever this flag says)
@@ -321,7 +334,6 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
 #pragma unroll
   for (int i = 0; i < GTE_MAX_DYN; ++i) job.cur[i] = 0.0f;
   bool ended = false;
-  if (px_out) px_out->idx = -2;  // "nothing to store" unless this lane steps or resets
 
   if (MODE == MODE_RESET) {
     if (active && (p.mask == nullptr || p.mask[e] != 0)) {
@@ -351,7 +363,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
     EnvRegs& s = carried ? *carried : s_own;
     PriceCarry c_own = {0.0, 0.0, -1, 0};
     PriceCarry& c = pc ? *pc : c_own;
-    if (!carried) load_state(p, e, s, pc ? nullptr : &c);
+    if (!carried) load_state(p, e, s, (pc || !GTE_EXP_PRICE_CACHE) ? nullptr : &c);
     int32_t action = action_in ? *action_in : p.actions[e];
     GTE_STAMP(2);  // record + action arrived
     // positions[position_index] raises IndexError in the reference (:234); a device-side
@@ -403,14 +415,26 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
         // descriptor -> price loads every step used to start with
         const DatasetDesc* dp = p.ds + s.dsi;
         const int32_t T = (int32_t)dp->T;
+        if (s.ds_T != T) p.rec[e].ds_T = T;
         s.ds_T = T;
-        p.rec[e].ds_T = T;
-        const double* cl = dp->close;
-        c.cur = cl[s.idx];
-        c.next = cl[s.idx + 1 < T ? s.idx + 1 : s.idx];
+        const uint64_t cl = (uint64_t)dp->close;
+        c.cur = load_global<double>(cl, s.idx);
+        c.next = load_global<double>(cl, s.idx + 1 < T ? s.idx + 1 : s.idx);
         c.idx = s.idx; c.dsi = s.dsi;
       }
       const int32_t d_T = s.ds_T;
+      // The price the step AFTER the next one values at, close[idx + 2], asked for NOW: its address
+      // needs nothing but the record, and the fp64 arithmetic below covers its latency, so that it
+      // can be stored with the record before the barrier.  (Asked for after the arithmetic and
+      // stored behind the barrier, wave 0's two scattered stores landed in the middle of the
+      // other waves' copy traffic: 48.9 us per step instead of 40.8, profiles/r03_price_cache_ab.log.)
+      const bool ahead = (GTE_EXP_PRICE_CACHE || pc) && s.idx + 2 < d_T;
+      double px_ahead = 0.0;
+      if (ahead) {
+        const double* cl = close0;
+        if (carried) { const float* unused; dataset_pointers(p, s.dsi, unused, cl); }
+        px_ahead = load_global<double>((uint64_t)cl, s.idx + 2);
+      }
       if (action >= 0) {  // :234 -> :213-215: trade only when the position VALUE differs
         const double position = position_value(p, pos_lds, action);
         if (position != position_value(p, pos_lds, s.pos)) {
@@ -422,13 +446,10 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
       s.step += 1;  // :236
       if (p.lo_pos) fill_limit_orders(p, e, p.ds + s.dsi, s);  // :238
       const double price = c.next;  // :239 close[idx] at the new row
-      // this step's valuation price is the next step's trade price; ask for the one after (consumed
-      // by the record store only)
+      // this step's valuation price is the next step's trade price; the one after was asked for above
       c.cur = price;
       c.idx = s.idx;
-      const double* cl = close0;
-      if (carried) { const float* unused; dataset_pointers(p, s.dsi, unused, cl); }
-      c.next = (s.idx + 1 < d_T) ? cl[s.idx + 1] : price;
+      c.next = ahead ? px_ahead : price;
       GTE_STAMP(3);  // positions, trade, prices: nothing arrived from memory since stamp 2
       s.q.ia = pymax0(-s.q.asset) * p.rate;   // update_interest, portfolio.py:44-46
       s.q.ifi = pymax0(-s.q.fiat) * p.rate;
@@ -479,8 +500,7 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
     if (pv_out) *pv_out = s.pv;
     if (write_record) {
       store_state(p, e, s);
-      if (px_out) *px_out = c;                       // stored by the caller, after its barrier
-      else if (c.idx >= 0) store_prices(&p.rec[e], c);
+      if ((GTE_EXP_PRICE_CACHE || pc) && c.idx >= 0) store_prices(&p.rec[e], c);
     }
     if (so) {
       so->idx = s.idx; so->step = s.step; so->pos = s.pos; so->dsi = s.dsi;
@@ -535,16 +555,6 @@ __device__ inline void store_out(T* dst, const T& v) {
   }
 }
 
-// The window's source pointer travels through LDS as a 64-bit integer, which makes the
-// compiler forget that it points to global memory: it then emits flat_load, and flat
-// loads count on vmcnt AND lgkmcnt (every LDS read in the loop waits for them).  Cast
-// back to the global address space explicitly.
-template <typename T>
-__device__ inline T load_global(uint64_t base, int64_t index) {
-  typedef const T __attribute__((address_space(1))) * gptr_t;
-  return ((gptr_t)base)[index];
-}
-
 // Put nd dynamic values x[0..nd) into vector v, which is the LAST vector of a window row.
 // With 16-byte vectors F_obs % 4 == 0 and nd <= 4, so the dynamic columns are exactly the
 // last nd components of that vector: a wave-uniform switch, no per-component compares.
@@ -589,12 +599,14 @@ struct WgLds {
 
 __device__ inline WgLds carve_lds(unsigned char* base, int EPB, bool with_final) {
   WgLds L;
+  // (offsets only, never an integer round trip: a pointer rebuilt from an integer loses its LDS
+  // address space, and every access through it — the staged rings in the copy loop — becomes a
+  // FLAT instruction: measured 52 us per step instead of 39)
   L.job = (JobRec*)base;                   base += 16 * EPB;
   L.pos = (double*)base;                   base += 8 * GTE_MAX_POSITIONS;
+  L.fin = (FinalJob*)base;                 base += with_final ? sizeof(FinalJob) * EPB : 0;  // 8-byte aligned
   L.cur = (float*)base;                    base += 4 * GTE_MAX_DYN * EPB;
   L.idx = (int32_t*)base;                  base += 4 * EPB;
-  base = (unsigned char*)(((uintptr_t)base + 15) & ~(uintptr_t)15);  // FinalJob holds a pointer
-  L.fin = (FinalJob*)base;                 base += with_final ? sizeof(FinalJob) * EPB : 0;
   L.staged = (float*)base;
   return L;
 }
@@ -877,9 +889,6 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
 #endif
 
   // ---- phase A
-  PriceCarry px;  // the prices the next step starts from: stored behind the barrier (wave-uniform use)
-  px.idx = -2;
-  int px_env = 0;
   if (!COOP || wib == 0) {  // wave-uniform
     const int s = COOP ? lane : wib * p.epw + lane;  // LDS slot = env within the workgroup
     const bool owns = COOP ? (lane < EPB) : (lane < p.epw);
@@ -888,15 +897,14 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
     // positions[] into LDS: the load is issued with the perm / record loads, and the state machine
     // then looks positions up in LDS instead of waiting for a global load behind the record
     // (LDS operations of one wave execute in order; every phase-A wave writes the same values)
-    const double* pos_lds = nullptr;
-    if (MODE == MODE_STEP) {
+    lds_f64_ptr pos_lds = nullptr;
+    if (MODE == MODE_STEP && GTE_EXP_POS_LDS) {
       if (lane < p.P) L.pos[lane] = p.positions[lane];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      pos_lds = L.pos;
+      pos_lds = (lds_f64_ptr)L.pos;
     }
-    px_env = e;
     ObsJob job;
     FinalJob fin;
 #ifndef GTE_HOT_ONLY  // p.log: hot_tu_covers() keeps such launches off the isolated TUs
@@ -906,7 +914,7 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
       // second launch reading everything back (4.5 us per step)
       StepOut so = {};
       phase_a<MODE>(p, e, active, lane, job, p.final_obs ? &fin : nullptr, true, nullptr, nullptr, nullptr,
-                    true, nullptr, &so, &px, pos_lds);
+                    true, nullptr, &so, pos_lds);
       if (active) {
         const int64_t k = p.log_row_base + e;
         p.log.idx[k] = so.idx; p.log.step[k] = so.step; p.log.pos[k] = so.pos; p.log.dsi[k] = so.dsi;
@@ -918,18 +926,22 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
     } else
 #endif
     phase_a<MODE>(p, e, active, lane, job, p.final_obs ? &fin : nullptr, true, nullptr, nullptr, nullptr,
-                  true, nullptr, nullptr, &px, pos_lds);
+                  true, nullptr, nullptr, pos_lds);
     if (owns) publish_job(L, s, job);  // slots past the last env get flags = 0
     if (owns && p.final_obs) L.fin[s] = fin;
   }
   // Only LDS has to be visible across the barrier (jobs, env ids, staged rings): nothing
   // after it reads global memory written before it in this launch.  __syncthreads() would
   // also drain wave 0's global stores (record, outputs, ring: 2.5 us in the timeline).
+#if defined(GTE_EXP_DRAIN) && GTE_EXP_DRAIN
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (A/B: stores drained first)
+#else
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+#if defined(GTE_EXP_PAD) && GTE_EXP_PAD > 0  // (A/B: shifts the address of the copy loop, nothing else)
+  asm volatile(".rept %0\n\ts_nop 0\n\t.endr" ::"n"(GTE_EXP_PAD));
+#endif
   GTE_STAMP(6);
-  // the next step's prices into the record (EnvRec.px_*): the load they wait for was the last
-  // thing phase A asked for; here nothing but this store depends on it
-  if (MODE == MODE_STEP && (!COOP || wib == 0) && px.idx >= 0) store_prices(&p.rec[px_env], px);
 
   // ---- phase B: each wave gathers the windows of its own EPW envs
   if (n_env <= 0 || (p.debug & 1)) return;
@@ -1070,7 +1082,7 @@ static uint64_t magic40(uint32_t d) { return ((1ull << 40) + d - 1) / d; }
 
 size_t lds_bytes(const Params& p, int stage) {
   const size_t EPB = (size_t)p.epw * GTE_WAVES;
-  size_t b = EPB * (16 + 4 * GTE_MAX_DYN + 4) + 8 * GTE_MAX_POSITIONS + 16 +
+  size_t b = EPB * (16 + 4 * GTE_MAX_DYN + 4) + 8 * GTE_MAX_POSITIONS +
              (p.final_obs ? EPB * sizeof(FinalJob) : 0);
   if (stage) b += EPB * (size_t)p.W * (size_t)(p.nd ? p.nd : 1) * 4;
   return b;

@@ -17,7 +17,8 @@ def main():
     import torch
     from gym_trading_env_amd import _abi
     from gym_trading_env_amd.batched import BatchedTradingEnv
-    lib_path = os.path.join(os.path.dirname(_abi.LIB_PATH), "libgte_stamps.so")
+    lib_path = os.path.join(os.path.dirname(_abi.LIB_PATH), sys.argv[1] if len(sys.argv) > 1 else "libgte_stamps.so")
+    print(f"# {os.path.basename(lib_path)}")
     wl = bench.WORKLOADS["c3"]
     N = wl["envs"]
     feat, close = bench.synthetic_dataset(0, wl["T"], wl["n_static"])
