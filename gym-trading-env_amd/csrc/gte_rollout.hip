@@ -252,11 +252,11 @@ __device__ __forceinline__ void resident_group(const Params& p0, const RolloutAr
   const bool active = owns && lane < n_wg;
   const int e0 = active ? (p0.perm ? p0.perm[wg_first + lane] : wg_first + lane) : 0;
   EnvRegs s = {};
-  PriceCarry pc = {0.0, 0.0, -1, 0};
-  if (active) load_state(p0, e0, s, &pc);  // (incl. the prices the record knows one step ahead)
+  if (active) load_state(p0, e0, s);
   int32_t act = active ? r.actions[e0] : -1;  // the next step's action, loaded one step ahead
   uint64_t prev_src = 0;
   int32_t prev_nz = -1;
+  PriceCarry pc = {0.0, 0.0, -1, 0};
   ObsJob job;
 
   auto run_a = [&](int k) {  // phase A of step k (wave 0), from and into the registers
@@ -477,9 +477,9 @@ __global__ __launch_bounds__(256) void gte_rollout_state_kernel(const Params p0,
   const bool active = lane < epw && slot < p0.N;
   const int e = active ? (p0.perm ? p0.perm[slot] : slot) : 0;
   EnvRegs s = {};
-  PriceCarry pc = {0.0, 0.0, -1, 0};
-  if (active) load_state(p0, e, s, &pc);
+  if (active) load_state(p0, e, s);
   int32_t act = active ? r.actions[e] : -1;
+  PriceCarry pc = {0.0, 0.0, -1, 0};
   ObsJob job;
   auto run_a = [&](int k) {
     const Params p = step_params(p0, r, k);
