@@ -147,6 +147,9 @@ class BatchedTradingEnv(_VectorEnvBase):
         # views of the library's pinned staging buffer, overwritten by the next call — no
         # 168 MB allocation + copy per step at the headline shape
         self.copy = bool(copy)
+        # verbose > 0 with a trajectory log: the reference's episode-end line (environments.py
+        # :269-271, :289-294) for the envs that finished, at most this many lines per step
+        self.verbose_max_lines = 16
         self.return_slots = int(return_slots)
         if self.return_slots < 1 or (self.return_slots > 1 and output != "torch"):
             raise ValueError("return_slots must be >= 1 (and > 1 only with output='torch')")
@@ -923,8 +926,31 @@ class BatchedTradingEnv(_VectorEnvBase):
         host->device copy."""
         self._launch_step(actions)
         self._apply_callables(after_reset=False)
+        if self.verbose > 0 and self.cfg.log_steps > 0:
+            self.log()
         obs, reward, term, trunc = self._results()
         return obs, reward, term, trunc, LazyInfo(self)
+
+    def log(self):
+        """`TradingEnv.log` after `calculate_metrics` (environments.py:269-271, :279-294) for the
+        envs whose episode ended in the last step: one line each, the reference's text —
+        "Market Return : ..   |   Portfolio Return : ..   |   " plus every `add_metric` entry.  A
+        batch can end hundreds of episodes per step, so at most `verbose_max_lines` lines are
+        printed, then a count.  Costs a device synchronisation, which is why `step()` only does it
+        when a trajectory log exists (``log_steps`` > 0: an env set up for metrics, not the bare
+        hot path) and `verbose` > 0.  In same-step mode it needs ``final_obs`` (the terminal
+        records); without them the finished episodes' final state is gone and nothing is printed."""
+        if self.verbose <= 0:
+            return
+        if self.cfg.autoreset == _abi.AUTORESET_SAME_STEP and not self.cfg.final_obs:
+            return
+        m = self.episode_metrics()
+        n = len(m["env_ids"])
+        names = ["Market Return", "Portfolio Return"] + [x["name"] for x in self.log_metrics]
+        for j in range(min(n, self.verbose_max_lines)):
+            print("".join(f"{k} : {m[k][j]}   |   " for k in names))
+        if n > self.verbose_max_lines:
+            print(f"... and {n - self.verbose_max_lines} more episodes ended in this step")
 
     def _launch_step(self, actions):
         """The launch half of step(): nothing is copied back."""
