@@ -233,6 +233,20 @@ class BatchedTradingEnv(_VectorEnvBase):
         self._out = _abi.GteOutputs()
         _abi.check(self._lib, self._lib.gte_get_outputs(self._h, C.byref(self._out)))
         self._was_reset = False
+        if _VectorEnvBase is not object:
+            # gymnasium installed: run the base initialiser too (unpinned — gymnasium is not in the
+            # build / test images; >= 1.0 takes no arguments, 0.29 takes the three below), then put
+            # this class's own spaces back
+            keep = (self.observation_space, self.action_space)
+            try:
+                try:
+                    _VectorEnvBase.__init__(self)
+                except TypeError:
+                    _VectorEnvBase.__init__(self, self.num_envs, self.single_observation_space,
+                                            self.single_action_space)
+            except Exception:  # noqa: BLE001 - never let an optional base class break the env
+                pass
+            self.observation_space, self.action_space = keep
 
     @classmethod
     def from_dataset_dir(cls, dataset_dir: str, num_envs: int, *args,
