@@ -486,6 +486,10 @@ int gte_create(const gte_config* cfg, gte_env** out) {
           for (int sl = b * EPB; sl < (b + 1) * EPB && sl < p.N; ++sl) slot_of_rank.push_back(sl);
       int nb = 8192 / p.D;
       nb = nb < 1 ? 1 : (nb > 4096 ? 4096 : nb);
+      if (const char* o = getenv("GTE_AFFINITY_BINS")) {  // tuning: total bins of the counting sort
+        nb = atoi(o) / p.D;
+        nb = nb < 1 ? 1 : nb;
+      }
       E->n_bins_per_ds = nb;
       int rc2 = GTE_OK;
       if (rc2 == GTE_OK) rc2 = dev_alloc(E, &E->d_perm, N, false);
