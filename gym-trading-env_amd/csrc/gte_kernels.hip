@@ -32,8 +32,6 @@
 // window gather + observation store.  See DESIGN.md for roofline and measurements.
 #include "gte_device.h"
 
-#include <type_traits>
-
 namespace gte {
 
 typedef float float4_t __attribute__((ext_vector_type(4)));
@@ -686,107 +684,6 @@ __device__ inline void phase_b(const Params& p, const WgLds& L, int s_first,
   }
 }
 
-// --- round-3 experiment (GTE_EXP_PIPE): the copy loop software-pipelined ----------------------------
-// vmcnt counts loads AND stores on this chip and retires them in issue order: a loop that issues
-// "U loads, wait, U stores" makes every pass's first wait also wait for the PREVIOUS pass's store
-// acknowledgements (a fabric round trip).  Here a pass issues the NEXT batch's loads, then the
-// current (already patched) batch's stores, then waits with vmcnt(U): only the U stores just issued
-// may stay in flight, i.e. the new data has arrived, and the stores drain behind the next pass's
-// address arithmetic.  hipcc's own s_waitcnt bookkeeping cannot express that (it falls back to
-// vmcnt(0) across the patch's divergent branches, with builtin loads / buffer-store builtins alike),
-// so loads, stores and the wait are inline asm; registers with a load in flight live only inside
-// one pass, between the load asm and the wait asm that ties them ("+v"), never across the loop edge.
-template <int NT>
-__device__ inline void store_vec4_asm(float4_t* dst, const float4_t& v) {
-  if constexpr (NT == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v));
-  else if constexpr (NT == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v));
-  else asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v));
-}
-
-template <int NT, int STAGE, int U>
-__device__ inline void phase_b_pipelined(const Params& p, const WgLds& L, int s_first, int n_env,
-                                         int lane, uint64_t vpe_magic, uint64_t fv_magic) {
-  static_assert(U == 2 || U == 3 || U == 4, "U loads in flight per lane");
-  constexpr int VEC = 4;
-  const uint32_t V = (uint32_t)(p.W * p.Fobs);
-  const uint32_t VPE = V / VEC, FV = (uint32_t)p.Fobs / VEC;
-  const uint32_t total = (uint32_t)n_env * VPE;
-  const uint64_t dummy = (uint64_t)p.positions;  // lanes without work load 16 harmless bytes
-  struct Meta {  // where a batch's vectors go and how they are patched (plain values, no load in flight)
-    uint32_t jj[U], ee[U], mm[U];
-    int32_t env[U];
-    bool ok[U];
-  };
-  auto locate = [&](uint32_t k0, Meta& m, uint64_t (&src)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t k = k0 + (uint32_t)u * 64u + (uint32_t)lane;
-      const bool in = k < total;
-      const uint32_t kk = in ? k : 0u;
-      m.ee[u] = fastdiv40(kk, vpe_magic);
-      m.jj[u] = kk - m.ee[u] * VPE;
-      const JobRec j = L.job[s_first + (int)m.ee[u]];  // one ds_read_b128
-      m.mm[u] = j.meta;
-      m.env[u] = j.env;
-      m.ok[u] = in && (j.meta & 1u);
-      src[u] = m.ok[u] ? j.src + (uint64_t)m.jj[u] * 16u : dummy;
-    }
-  };
-  auto patch = [&](const Meta& m, float4_t (&v)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (!m.ok[u]) continue;
-      const uint32_t w = fastdiv40(m.jj[u], fv_magic);
-      const int col = (int)(m.jj[u] - w * FV) * VEC;
-      const float* ring_e = p.ring + (int64_t)m.env[u] * p.depth * p.nd;
-      patch_dynamic<VEC, STAGE>(p, L, v[u], s_first + (int)m.ee[u], m.mm[u], ring_e, (int)w, col);
-    }
-  };
-  auto issue_loads = [&](const uint64_t (&src)[U], float4_t (&v)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[u]) : "v"(src[u]));
-  };
-  auto issue_stores = [&](const Meta& m, const float4_t (&v)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (m.ok[u]) store_vec4_asm<NT>((float4_t*)(p.obs + (int64_t)m.env[u] * V + (int64_t)m.jj[u] * VEC), v[u]);
-  };
-  auto arrived = [&](float4_t (&v)[U], auto pending_younger) {  // s_waitcnt vmcnt(n), tying the registers
-    constexpr int n = decltype(pending_younger)::value;  // std::integral_constant
-    if constexpr (U == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(v[0]), "+v"(v[1]) : "n"(n));
-    else if constexpr (U == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]) : "n"(n));
-    else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "n"(n));
-  };
-  using N0 = std::integral_constant<int, 0>;
-  using NU = std::integral_constant<int, U>;
-  const uint32_t STEP = 64u * U;
-  if (total == 0u) return;
-  // prologue: the first batch, loaded and patched
-  Meta cur;
-  float4_t cv[U];
-  {
-    uint64_t src[U];
-    locate(0u, cur, src);
-    issue_loads(src, cv);
-    arrived(cv, N0{});
-    patch(cur, cv);
-  }
-  for (uint32_t k0 = STEP; k0 < total; k0 += STEP) {  // wave-uniform
-    Meta nxt;
-    uint64_t src[U];
-    float4_t nv[U];
-    locate(k0, nxt, src);
-    issue_loads(src, nv);       // the next batch's loads first ...
-    issue_stores(cur, cv);      // ... then this batch's stores ...
-    arrived(nv, NU{});          // ... and only those stores may still be in flight: nv has arrived
-    patch(nxt, nv);
-    cur = nxt;
-#pragma unroll
-    for (int u = 0; u < U; ++u) cv[u] = nv[u];
-  }
-  issue_stores(cur, cv);
-}
-
 // zero the dynamic store of envs that switched dataset in persist mode (the
 // reference rebuilds _obs_array in _set_df), except the current row's slot
 __device__ inline void zero_fresh_stores(const Params& p, const WgLds& L,
@@ -879,12 +776,6 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
   const int wg_first = blockIdx.x * EPB;
   if (wg_first >= p.N) return;  // whole workgroup exits together (before any barrier)
   const int n_wg = min(EPB, p.N - wg_first);
-#if defined(GTE_EXP_STAGGER) && GTE_EXP_STAGGER > 0
-  // (A/B build: the k-th workgroup of a CU starts k * GTE_EXP_STAGGER * 64 cycles late, so that the
-  // phase A of the later ones runs beside the copies of the earlier ones)
-  if (MODE == MODE_STEP)
-    for (int d = (blockIdx.x >> 8) * GTE_EXP_STAGGER; d > 0; d -= 100) __builtin_amdgcn_s_sleep(100);
-#endif
   GTE_STAMP(0);
   const WgLds L = carve_lds(gte_smem, EPB, p.final_obs != nullptr);
   const int s_first = wib * p.epw;
@@ -962,11 +853,6 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-#if defined(GTE_EXP_PIPE) && GTE_EXP_PIPE > 0
-  if constexpr (VEC == 4 && MODE == MODE_STEP && COOP && STAGE == STAGE_RAW)
-    phase_b_pipelined<NT, STAGE, GTE_EXP_PIPE>(p, L, s_first, n_env, lane, vpe_magic, fv_magic);
-  else
-#endif
   phase_b<VEC, NT, STAGE, GTE_GATHER_U>(p, L, s_first, n_env, lane, vpe_magic, fv_magic);
   GTE_STAMP(7);
   if (MODE == MODE_STEP && p.final_obs) final_windows<VEC>(p, L, s_first, n_env, lane, fv_magic);
