@@ -457,6 +457,8 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   E->coop = (epw * GTE_WAVES <= 64) && !(cfg->kernel_variant & 1);
   E->stage = (p.nd > 0 && gte::lds_bytes(p, 1) <= 48 * 1024 && !(cfg->kernel_variant & 2))
                  ? (p.persist ? 2 : 1) : 0;
+  // the lean copy loop (gte_kernels.hip): 16-byte vectors with the raw rings staged in LDS
+  p.lean_rows = (E->vec == 4 && E->stage == 1 && !p.persist && !(cfg->kernel_variant & 4096)) ? 1 : 0;
   const int64_t waves = ((int64_t)p.N + epw - 1) / epw;
   E->threads = 64 * GTE_WAVES;
   E->blocks = (int)((waves + GTE_WAVES - 1) / GTE_WAVES);

@@ -93,6 +93,7 @@ struct Params {
   const int32_t* perm; // processing slot -> env id (L2-affinity order), or null = identity
   int32_t epw;         // environments per wavefront
   int32_t debug;       // gte_config.debug_flags (timing ablations)
+  int32_t lean_rows;   // != 0: full waves of 16-byte-vector windows take the lean copy loop (gte_kernels.hip)
   // --- trajectory row written by THIS launch's phase A (a gte_step with log_steps > 0; the
   // shared-TU step kernel only).  log.idx == null: none (the host appends it with gte_log_kernel)
   LogArrays log;

@@ -458,7 +458,12 @@ __device__ inline void store_out(T* dst, const T& v) {
   if constexpr (NT == 2 && sizeof(T) == 16) {
     // no "memory" clobber: nothing in the kernel reads obs back, and volatile asms keep
     // their order among themselves (the s_waitcnt before the barrier stays behind them)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v));
+    // s_nop 1: a VMEM store of more than 64 bits reads its data registers for a couple of cycles
+    // after it issues; a VALU write to them in that window corrupts the stored value (gfx9 / CDNA
+    // hazard "VMEM store > 8 bytes followed by a write of the VGPRs holding the data").  hipcc pads
+    // its own stores, but it does not look inside inline asm: without the two wait states here the
+    // lean copy loop stored the next address computation's low words in place of x, y.
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v));
   } else if constexpr (NT == 2) {
     const float f = __builtin_bit_cast(float, v);  // 1-element vector: plain VGPR operand
     asm volatile("global_store_dword %0, %1, off sc1" ::"v"(dst), "v"(f));
@@ -517,7 +522,8 @@ struct WgLds {
   int32_t* idx;     // [EPB] current row (persist mode's zero-fill needs it)
   float* cur;       // [EPB][GTE_MAX_DYN] dynamic features of the current row
   FinalJob* fin;    // [EPB] terminal windows (only when p.final_obs)
-  float* staged;    // [EPB][W][nd]
+  float* staged;    // [EPB][W][nd]: the raw rings; the lean copy loop resolves a wave's part IN
+                    // PLACE into window order (rotation / zero rows / current row applied)
 };
 
 __device__ inline WgLds carve_lds(unsigned char* base, int EPB, bool with_final) {
@@ -680,6 +686,112 @@ __device__ inline void phase_b(const Params& p, const WgLds& L, int s_first,
       const float* ring_e = p.ring + (int64_t)env[u] * p.depth * p.nd;
       patch_dynamic<VEC, STAGE>(p, L, v[u], s, mm[u], ring_e, (int)w, col);
       store_out<NT>((vec_t*)(p.obs + (int64_t)env[u] * V + (int64_t)jj[u] * VEC), v[u]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Lean copy loop (round 3).  The SQ counters show the step kernel's SIMDs ~75 % issue-busy: the
+// generic loop above spends ~67 VALU instructions per wave-vector (two 40-bit magic divisions,
+// 64-bit address arithmetic, per-vector branches, the dynamic-column patch executed by all 64 lanes
+// because every wave instruction contains some row's last vector), i.e. the copy is bound by
+// instruction issue as much as by memory.  For the common case — a full wave of envs that all copy,
+// whole number of passes — this version does the same copy with a third of the instructions:
+//   * the dynamic values of every window row are resolved ONCE per env into LDS (rotation, zero
+//     rows, current row; already placed in the vector components they occupy), so patching a
+//     vector is one ds_read_b128 and a per-lane select, no branch;
+//   * a lane walks its vectors k = lane + 64 q with running (env, vector-in-env, row, vector-in-row)
+//     counters instead of dividing;
+//   * no per-vector validity branches (the caller checks the whole wave once).
+// Results are the generic loop's, bit for bit (the parity suite runs through it).
+constexpr int LEAN_MAX_ROWS = 512;  // window rows of one wave's envs the in-place resolve holds in registers
+
+template <int ND>
+__device__ inline void resolve_dynamic_rows(const Params& p, const WgLds& L, int s_first, int n_env,
+                                            int lane, uint64_t wnd_magic) {
+  const uint32_t W = (uint32_t)p.W;
+  const uint32_t rows = (uint32_t)n_env * W;  // <= LEAN_MAX_ROWS (the caller checks)
+  float x[LEAN_MAX_ROWS / 64][ND];
+  // every value is read (from the raw rings / the current-row values) before any is written back:
+  // a wave's envs own a contiguous part of L.staged that no other wave touches
+#pragma unroll
+  for (int q = 0; q < LEAN_MAX_ROWS / 64; ++q) {
+    if (64u * (uint32_t)q >= rows) break;  // wave-uniform
+    const uint32_t r = (uint32_t)lane + 64u * (uint32_t)q;
+    const bool in = r < rows;
+    const uint32_t rr = in ? r : 0u;
+    const uint32_t el = fastdiv40(rr * (uint32_t)ND, wnd_magic);  // rr / W  (wnd_magic divides by W * nd)
+    const uint32_t w = rr - el * W;
+    const int s = s_first + (int)el;
+    const uint32_t m = L.job[s].meta;
+    int32_t slot = meta_slot0(m) + (int32_t)w;
+    if (slot >= (int32_t)W) slot -= (int32_t)W;
+    const bool is_cur = (w == W - 1u);
+    const bool zero = !is_cur && (int)w < meta_n_zero(m);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const float* a = is_cur ? &L.cur[s * GTE_MAX_DYN + i] : &L.staged[((uint32_t)s * W + (uint32_t)slot) * ND + i];
+      x[q][i] = (zero || !in) ? 0.0f : *a;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int q = 0; q < LEAN_MAX_ROWS / 64; ++q) {
+    const uint32_t r = (uint32_t)lane + 64u * (uint32_t)q;
+    if (r < rows) {  // row r of the wave's part, in window order: env r / W, row r % W
+#pragma unroll
+      for (int i = 0; i < ND; ++i) L.staged[((uint32_t)s_first * W + r) * ND + i] = x[q][i];
+    }
+  }
+}
+
+#ifndef GTE_LEAN_U
+#define GTE_LEAN_U 4  // vectors in flight per lane in the lean copy loop
+#endif
+template <int NT, int ND>
+__device__ inline void phase_b_lean(const Params& p, const WgLds& L, int s_first, int n_env, int lane) {
+  constexpr int U = GTE_LEAN_U;
+  const uint32_t W = (uint32_t)p.W, FV = (uint32_t)p.Fobs / 4u, VPE = W * FV;
+  const uint32_t total = (uint32_t)n_env * VPE;          // a multiple of 64 * U (checked by the caller)
+  const uint32_t VB = VPE * 16u;                          // bytes per observation
+  // running position of this lane's vector: env slot `ee`, vector in env `jj`, row `w`, vector in row `r`
+  uint32_t ee = (uint32_t)lane / VPE;                     // VPE >= 64: 0
+  uint32_t jj = (uint32_t)lane - ee * VPE;
+  uint32_t w = jj / FV, r = jj - w * FV;
+  const uint32_t w_inc = 64u / FV, r_inc = 64u - w_inc * FV;  // one step of 64 vectors
+  char* const obs = (char*)p.obs;
+  // (one fixed pass shape, the loop written out: as a generic lambda with a tail pass for other
+  // multiples of 64 the same code compiled 5 % slower at config 5)
+  for (uint32_t k0 = 0u; k0 < total; k0 += 64u * U) {
+    float4_t v[U];
+    float t[U][ND];
+    uint32_t jj16[U];
+    int32_t env[U];
+    bool last[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int s = s_first + (int)ee;
+      const JobRec j = L.job[s];                           // one ds_read_b128
+#pragma unroll
+      for (int c = 0; c < ND; ++c) t[u][c] = L.staged[((uint32_t)s * W + w) * ND + c];  // one LDS read
+      env[u] = j.env;
+      jj16[u] = jj * 16u;
+      last[u] = (r == FV - 1u);
+      v[u] = load_global<float4_t>(j.src, (int64_t)jj);
+      // advance by 64 vectors
+      jj += 64u; w += w_inc; r += r_inc;
+      if (r >= FV) { r -= FV; w += 1u; }
+      if (jj >= VPE) { jj -= VPE; ee += 1u; w -= W; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float4_t o = v[u];
+      // the dynamic columns are the last ND components of a row's last vector
+#pragma unroll
+      for (int c = 0; c < ND; ++c) o[4 - ND + c] = last[u] ? t[u][c] : o[4 - ND + c];
+      store_out<NT>((float4_t*)(obs + (uint64_t)(uint32_t)env[u] * VB + jj16[u]), o);
     }
   }
 }
@@ -853,7 +965,32 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  phase_b<VEC, NT, STAGE, GTE_GATHER_U>(p, L, s_first, n_env, lane, vpe_magic, fv_magic);
+  bool lean = false;
+  if constexpr (MODE == MODE_STEP && VEC == 4 && STAGE == STAGE_RAW) {
+    // the lean loop takes whole waves of envs that all copy, in whole passes of U wave instructions
+    // (windows of at least one wave instruction: the running counters wrap at most once per step of 64)
+    if (p.lean_rows > 0 && n_env == p.epw && n_env * p.W <= LEAN_MAX_ROWS && p.W * p.Fobs / 4 >= 64 &&
+        ((uint32_t)n_env * (uint32_t)(p.W * p.Fobs / 4)) % (64u * GTE_LEAN_U) == 0u && !p.debug &&
+        __ballot(lane < n_env && !(L.job[s_first + (lane < n_env ? lane : 0)].meta & 1u)) == 0ull) {
+      switch (p.nd) {  // wave-uniform, outside the loops
+        case 1: resolve_dynamic_rows<1>(p, L, s_first, n_env, lane, wnd_magic); break;
+        case 2: resolve_dynamic_rows<2>(p, L, s_first, n_env, lane, wnd_magic); break;
+        case 3: resolve_dynamic_rows<3>(p, L, s_first, n_env, lane, wnd_magic); break;
+        default: resolve_dynamic_rows<4>(p, L, s_first, n_env, lane, wnd_magic); break;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (this wave's own LDS writes, read back below)
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      switch (p.nd) {
+        case 1: phase_b_lean<NT, 1>(p, L, s_first, n_env, lane); break;
+        case 2: phase_b_lean<NT, 2>(p, L, s_first, n_env, lane); break;
+        case 3: phase_b_lean<NT, 3>(p, L, s_first, n_env, lane); break;
+        default: phase_b_lean<NT, 4>(p, L, s_first, n_env, lane); break;
+      }
+      lean = true;
+    }
+  }
+  if (!lean) phase_b<VEC, NT, STAGE, GTE_GATHER_U>(p, L, s_first, n_env, lane, vpe_magic, fv_magic);
   GTE_STAMP(7);
   if (MODE == MODE_STEP && p.final_obs) final_windows<VEC>(p, L, s_first, n_env, lane, fv_magic);
 }

@@ -127,7 +127,9 @@ typedef struct gte_config {
                                window-resident one, 1024 = gte_step always appends
                                the trajectory row with a separate small launch, 2048 =
                                always inside the step kernel (default: whichever
-                               measured faster for the batch size)                  */
+                               measured faster for the batch size), 4096 = always the
+                               generic copy loop (not the lean one that full waves of
+                               16-byte-vector windows take)                         */
   int32_t debug_flags;      /* timing ablations only (results become wrong):
                                1 = skip the observation gather, 2 = skip the
                                dynamic-column patch, 8 = skip the window loads

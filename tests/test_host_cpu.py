@@ -252,6 +252,27 @@ def test_features_compiled_out_of_the_hot_translation_units_are_guarded():
             assert "if (!hot_tu_covers(p)) return hipErrorInvalidValue;" in m.group(0), m.group(0)[:80]
 
 
+def test_inline_asm_wide_stores_carry_their_wait_states():
+    """A VMEM store of more than 64 bits keeps reading its data VGPRs for a couple of cycles after
+    it issues; hipcc pads its own stores but does not look inside inline asm, so an asm
+    `global_store_dwordx3/x4` must end with `s_nop 1` INSIDE its string — otherwise the compiler's
+    next VALU instruction may overwrite the data before the store has read it (round 3: the lean
+    copy loop stored address words in place of x, y until this was added; the generic loop had
+    been getting away with it by luck of scheduling)."""
+    csrc = os.path.join(ROOT, "gym-trading-env_amd", "csrc")
+    found = 0
+    for name in os.listdir(csrc):
+        if not name.endswith((".hip", ".h")):
+            continue
+        src = open(os.path.join(csrc, name)).read()
+        for m in re.finditer(r'asm\s+volatile\(\s*"([^"]*(?:"\s*"[^"]*)*)"', src):
+            text = m.group(1)
+            if re.search(r"(global|buffer|flat)_store_dwordx[34]", text):
+                found += 1
+                assert re.search(r"_store_dwordx[34][^\\]*\\n\\ts_nop 1", text), (name, text)
+    assert found >= 1
+
+
 def test_integration_md_stub_matches_the_abi():
     """The ctypes stub INTEGRATION.md shows a maintainer of the reference is not prose: its
     gte_config must have the fields, order and size of the real one."""
