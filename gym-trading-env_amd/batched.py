@@ -147,9 +147,14 @@ class BatchedTradingEnv(_VectorEnvBase):
         # views of the library's pinned staging buffer, overwritten by the next call — no
         # 168 MB allocation + copy per step at the headline shape
         self.copy = bool(copy)
-        # verbose > 0 with a trajectory log: the reference's episode-end line (environments.py
-        # :269-271, :289-294) for the envs that finished, at most this many lines per step
+        # verbose > 0 with a trajectory log the USER asked for: the reference's episode-end line
+        # (environments.py:269-271, :289-294) for the envs that finished — at most
+        # `verbose_max_lines` per report and one report per `verbose_interval` seconds (a report
+        # costs a device synchronisation; 0 = after every step)
         self.verbose_max_lines = 16
+        self.verbose_interval = 1.0
+        self._last_report = 0.0
+        self._user_log = int(log_steps) > 0
         self.return_slots = int(return_slots)
         if self.return_slots < 1 or (self.return_slots > 1 and output != "torch"):
             raise ValueError("return_slots must be >= 1 (and > 1 only with output='torch')")
@@ -940,8 +945,12 @@ class BatchedTradingEnv(_VectorEnvBase):
         host->device copy."""
         self._launch_step(actions)
         self._apply_callables(after_reset=False)
-        if self.verbose > 0 and self.cfg.log_steps > 0:
-            self.log()
+        if self.verbose > 0 and self._user_log:
+            import time
+            now = time.monotonic()
+            if now - self._last_report >= self.verbose_interval:
+                self._last_report = now
+                self.log()
         obs, reward, term, trunc = self._results()
         return obs, reward, term, trunc, LazyInfo(self)
 
@@ -951,8 +960,10 @@ class BatchedTradingEnv(_VectorEnvBase):
         "Market Return : ..   |   Portfolio Return : ..   |   " plus every `add_metric` entry.  A
         batch can end hundreds of episodes per step, so at most `verbose_max_lines` lines are
         printed, then a count.  Costs a device synchronisation, which is why `step()` only does it
-        when a trajectory log exists (``log_steps`` > 0: an env set up for metrics, not the bare
-        hot path) and `verbose` > 0.  In same-step mode it needs ``final_obs`` (the terminal
+        when the user asked for a trajectory log (``log_steps`` > 0: an env set up for metrics, not
+        the bare hot path, and not the 2-row log a Python callable brings with it), `verbose` > 0,
+        and at most once per `verbose_interval` seconds (episodes that end between two reports
+        are not listed; `episode_metrics()` after any step gives them all).  In same-step mode it needs ``final_obs`` (the terminal
         records); without them the finished episodes' final state is gone and nothing is printed."""
         if self.verbose <= 0:
             return

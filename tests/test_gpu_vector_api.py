@@ -774,6 +774,8 @@ def test_verbose_prints_the_reference_episode_end_lines(capsys):
     N = 8
     changes = lambda h: int(np.sum(np.diff(h["position"]) != 0))
     batch = gte.BatchedTradingEnv(df, N, autoreset="next_step", log_steps=128, output="numpy", **kw)
+    assert batch.verbose_interval == 1.0  # by default at most one report per second (a report synchronises)
+    batch.verbose_interval = 0            # here: after every step, like the reference
     batch.add_metric("Position Changes", changes)
     singles = []
     for e in range(N):
@@ -809,6 +811,7 @@ def test_verbose_prints_the_reference_episode_end_lines(capsys):
     big = gte.BatchedTradingEnv(df, 40, autoreset="next_step", log_steps=128, output="numpy",
                                 **dict(kw, max_episode_duration=5, initial_position="random"))
     big.verbose_max_lines = 3
+    big.verbose_interval = 0
     big.reset()
     capsys.readouterr()
     for k in range(4):
