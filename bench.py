@@ -169,7 +169,7 @@ def make_env(args, wl, N, rank, local_rank, return_slots=1):
     data = [synthetic_dataset((rank * D + d) if D > 1 else 0, wl["T"], wl["n_static"])
             for d in range(D)]
     tuning = dict(envs_per_wave=args.epw, kernel_variant=args.variant,
-                  affinity_period=args.affinity)
+                  affinity_period=args.affinity, debug_flags=getattr(args, "debug_flags", 0))
     if args.nt >= 0:
         tuning["nontemporal_obs"] = args.nt
     return BatchedTradingEnv(data if D > 1 else data[0], num_envs=N, seed=20240607,
@@ -346,6 +346,7 @@ def main():
     ap.add_argument("--nt", type=int, default=-1,
                     help="observation store policy: 0 plain, 1 nt, 2 sc1 (default: the library's)")
     ap.add_argument("--variant", type=int, default=0, help="kernel_variant bits (A/B timing)")
+    ap.add_argument("--debug-flags", type=int, default=0, help="gte_config.debug_flags (timing probes: results are wrong)")
     ap.add_argument("--affinity", type=int, default=0,
                     help="L2-affinity re-sort period in steps (0 = default 128, -1 = off)")
     ap.add_argument("--sync-episodes", action="store_true",

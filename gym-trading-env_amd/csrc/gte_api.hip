@@ -26,6 +26,8 @@ hipError_t launch_reset(const Params& p, int vec, int nt, bool coop, int stage, 
 size_t lds_bytes(const Params& p, int stage);
 hipError_t launch_step_hot(const Params& p, int blocks, int threads, size_t smem, hipStream_t stream);
 hipError_t launch_step_hot_nt(const Params& p, int blocks, int threads, size_t smem, hipStream_t stream);
+hipError_t launch_step5(const Params& p, int blocks, hipStream_t stream);
+hipError_t launch_step5_nt(const Params& p, int blocks, hipStream_t stream);
 int hot_blocks_per_cu(size_t smem);
 int hot_blocks_per_cu_nt(size_t smem);
 struct RolloutArgs {  // mirrors gte_rollout.hip
@@ -780,7 +782,17 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
   // (hot_tu_covers: the isolated instantiations have no terminal records and no trajectory row)
   const bool hot = E->vec == 4 && E->coop && E->stage == 1 && !(E->cfg.kernel_variant & 64) &&
                    gte::hot_tu_covers(p);
-  if (hot && E->cfg.nontemporal_obs == 2)
+  // the decoupled 5-wave kernel (phase A beside the predicted copies): the lean copy loop's shapes,
+  // whole workgroups only; kernel_variant 8192 keeps the 4-wave kernel
+  const int64_t vpe5 = (int64_t)p.W * p.Fobs / 4;
+  const bool step5 = hot && p.lean_rows && GTE_WAVES == 4 && !(E->cfg.kernel_variant & 8192) && !(p.debug & ~112) &&
+                     p.N % (p.epw * 4) == 0 && vpe5 >= 64 && (p.epw * vpe5) % 256 == 0 &&
+                     (int64_t)p.epw * p.W <= 512;
+  if (step5 && E->cfg.nontemporal_obs == 2)
+    HIPCHK(gte::launch_step5(p, p.N / (p.epw * 4), E->stream));
+  else if (step5 && E->cfg.nontemporal_obs == 1)
+    HIPCHK(gte::launch_step5_nt(p, p.N / (p.epw * 4), E->stream));
+  else if (hot && E->cfg.nontemporal_obs == 2)
     HIPCHK(gte::launch_step_hot(p, E->blocks, E->threads, gte::lds_bytes(p, E->stage), E->stream));
   else if (hot && E->cfg.nontemporal_obs == 1)
     HIPCHK(gte::launch_step_hot_nt(p, E->blocks, E->threads, gte::lds_bytes(p, E->stage), E->stream));

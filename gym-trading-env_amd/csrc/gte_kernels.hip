@@ -536,6 +536,13 @@ __device__ inline WgLds carve_lds(unsigned char* base, int EPB, bool with_final)
   return L;
 }
 
+// bytes of the classic LDS image (jobs, current values, rows, raw rings) of a workgroup of EPB envs,
+// rounded up to 16: where the decoupled kernel's extra arrays start (device copy of lds_bytes())
+__device__ __host__ inline size_t lds_bytes_classic(const Params& p, int EPB) {
+  size_t b = (size_t)EPB * (16 + 4 * GTE_MAX_DYN + 4) + (size_t)EPB * (size_t)p.W * (size_t)(p.nd ? p.nd : 1) * 4;
+  return (b + 15) & ~(size_t)15;
+}
+
 // phase A's lane publishes its env's job (the env id was written at kernel start)
 __device__ inline void publish_job(const WgLds& L, int slot, const ObsJob& job) {
   L.job[slot].src = (uint64_t)job.src;
@@ -993,6 +1000,148 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
   if (!lean) phase_b<VEC, NT, STAGE, GTE_GATHER_U>(p, L, s_first, n_env, lane, vpe_magic, fv_magic);
   GTE_STAMP(7);
   if (MODE == MODE_STEP && p.final_obs) final_windows<VEC>(p, L, s_first, n_env, lane, fv_magic);
+}
+
+// ---------------------------------------------------------------------------
+// Decoupled step kernel (round 3): phase A and the copies of the SAME step run side by side.
+//
+// In gte_kernel every copy waits ~8 us for its workgroup's phase A (dispatch ramp + dependent
+// loads + the fp64 chain) while the store path — the resource the step is bound by — idles.  But
+// what phase A decides about an observation is almost nothing: a running env's window is rows
+// idx+1-W+1 .. idx+1 of its table — known from the record alone — with the dynamic columns of the
+// older rows in its ring; only the CURRENT row's dynamic values (one 16-byte vector) and the
+// rare reset / episode end depend on the step.  So: 5 wavefronts per workgroup.
+//   wave 0      phase A for the workgroup's 4*epw envs, exactly as in gte_kernel; it publishes the
+//               real jobs to LDS, then issues its global stores (it copies nothing, so the slow
+//               service its scattered stores get beside the copy traffic delays nobody);
+//   waves 1-4   each PREDICTS the jobs of its epw envs from their records, stages + resolves their
+//               rings and copies the predicted windows with the lean loop at once;
+//   barrier;    each copy wave compares real and predicted jobs (source row, zero rows, ring
+//               rotation): equal -> it only rewrites each env's last vector (the current row's
+//               dynamic values); different for any of its envs (a reset, an episode end in
+//               same-step mode, a frozen env) -> it redoes its envs from the real jobs.
+// Same results as gte_kernel bit for bit by construction: whatever was predicted is checked
+// against what phase A published, and every vector that could differ is rewritten.
+// Shapes: the lean loop's (16-byte vectors, raw rings in LDS, whole passes), N a multiple of the
+// workgroup's envs, no terminal records / in-kernel log / persist; gte_step falls back otherwise.
+template <int NT>
+__global__ __launch_bounds__(320) void gte_step5_kernel(const Params p, const uint64_t vpe_magic,
+                                                        const uint64_t fv_magic, const uint64_t wnd_magic) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gte_smem[];
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;  // 0: phase A; 1..4: copy waves
+  if (blockIdx.x == 0 && threadIdx.x == 0) p.term_count_next[0] = 0;
+  const int EPB = p.epw * 4;
+  const int wg_first = blockIdx.x * EPB;  // (N % EPB == 0: the host checks)
+  const WgLds L = carve_lds(gte_smem, EPB, false);
+  // predicted jobs + a block of zeros standing in for the (unknown) current-row values
+  JobRec* pjob = (JobRec*)(gte_smem + lds_bytes_classic(p, EPB));
+  float* pcur = (float*)(pjob + EPB);
+  WgLds LP = L;
+  LP.job = pjob;
+  LP.cur = pcur;
+  const uint32_t W = (uint32_t)p.W, FV = (uint32_t)p.Fobs / 4u, VPE = W * FV, V = VPE * 4u;
+
+  if (wib == 0) {
+    // ---- phase A (lane = env of the workgroup)
+    const int s = lane;
+    const bool active = s < EPB;
+    const int e = active ? (p.perm ? p.perm[wg_first + s] : wg_first + s) : 0;
+    ObsJob job;
+    phase_a<MODE_STEP>(p, e, active, lane, job, nullptr);
+    if (active) publish_job(L, s, job);
+  } else {
+    // ---- copy wave: predict, stage, copy
+    const int s_first = (wib - 1) * p.epw;
+    const int n_env = p.epw;
+    int32_t e = 0;
+    if (lane < n_env) {
+      const int slot = wg_first + s_first + lane;
+      e = p.perm ? p.perm[slot] : slot;
+      L.job[s_first + lane].env = e;  // (publish_job leaves .env alone)
+      // the env's record: idx, dataset, start row, whether it is due a reset
+      const int4 a = reinterpret_cast<const int4*>(&p.rec[e])[0];  // idx, step, pos, dsi
+      const int4 b = reinterpret_cast<const int4*>(&p.rec[e])[1];  // start, episode, needs_reset, eps_on_ds
+      const int32_t idx = a.x + 1;                                  // :235, if the env just steps
+      const int32_t first = idx - (int32_t)W + 1;
+      int32_t nz = b.x - first;
+      nz = nz < 0 ? 0 : (nz > (int32_t)W - 1 ? (int32_t)W - 1 : nz);
+      JobRec j;
+      j.src = (uint64_t)(p.ds[a.w].feat + (int64_t)first * p.Fobs);
+      j.env = e;
+      // an env due a next-step reset moves to a row only phase A knows: meta 0 never matches a real job
+      j.meta = (b.z && p.autoreset == GTE_AUTORESET_NEXT_STEP) ? 0u : pack_meta(1, nz, (idx + 1) % (int32_t)W);
+      pjob[s_first + lane] = j;
+#pragma unroll
+      for (int i = 0; i < GTE_MAX_DYN; ++i) pcur[(s_first + lane) * GTE_MAX_DYN + i] = 0.0f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    stage_raw_rings(p, LP, s_first, n_env, lane, wnd_magic);
+    // predicted copies only when every env of the wave has a usable prediction (else: all after the barrier)
+    const bool predicted = __ballot(lane < n_env && !(pjob[s_first + (lane < n_env ? lane : 0)].meta & 1u)) == 0ull;
+    if (predicted && !(p.debug & 32)) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      switch (p.nd) {
+        case 1: resolve_dynamic_rows<1>(p, LP, s_first, n_env, lane, wnd_magic); break;
+        case 2: resolve_dynamic_rows<2>(p, LP, s_first, n_env, lane, wnd_magic); break;
+        case 3: resolve_dynamic_rows<3>(p, LP, s_first, n_env, lane, wnd_magic); break;
+        default: resolve_dynamic_rows<4>(p, LP, s_first, n_env, lane, wnd_magic); break;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      switch (p.nd) {
+        case 1: phase_b_lean<NT, 1>(p, LP, s_first, n_env, lane); break;
+        case 2: phase_b_lean<NT, 2>(p, LP, s_first, n_env, lane); break;
+        case 3: phase_b_lean<NT, 3>(p, LP, s_first, n_env, lane); break;
+        default: phase_b_lean<NT, 4>(p, LP, s_first, n_env, lane); break;
+      }
+    }
+  }
+  // real jobs (wave 0) and predicted copies (waves 1-4) are done; only LDS has to be visible
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (wib == 0) return;
+
+  // ---- fix-up
+  const int s_first = (wib - 1) * p.epw;
+  const int n_env = p.epw;
+  const int sl = s_first + (lane < n_env ? lane : 0);
+  const JobRec real = L.job[sl], pred = pjob[sl];
+  const bool same = real.src == pred.src && real.meta == pred.meta && (real.meta & 1u);
+  if (__ballot(lane < n_env && !same) == 0ull) {
+    // every prediction held: only the current row's dynamic values were unknown — the last vector
+    if (lane < n_env) {
+      float4_t v = load_global<float4_t>(real.src, (int64_t)(VPE - 1u));
+      float x[GTE_MAX_DYN];
+#pragma unroll
+      for (int i = 0; i < GTE_MAX_DYN; ++i) x[i] = L.cur[sl * GTE_MAX_DYN + i];
+      set_tail(v, p.nd, x);
+      store_out<NT>((float4_t*)(p.obs + (int64_t)real.env * V + (int64_t)(VPE - 1u) * 4), v);
+    }
+    return;
+  }
+  // some env of the wave reset / ended / froze: redo the wave's envs from the real jobs
+  if (p.debug & 64) {  // (diagnostic: what differed, into the first vector of the env's observation)
+    if (lane < n_env && !same) {
+      float4_t d;
+      d[0] = (float)(int64_t)(real.src - pred.src); d[1] = (float)real.meta; d[2] = (float)pred.meta; d[3] = -12345.0f;
+      *(float4_t*)(p.obs + (int64_t)real.env * V) = d;
+    }
+    return;
+  }
+  if (p.debug & 16) return;  // (timing probe)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  stage_raw_rings(p, L, s_first, n_env, lane, wnd_magic);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  phase_b<4, NT, STAGE_RAW, GTE_GATHER_U>(p, L, s_first, n_env, lane, vpe_magic, fv_magic);
 }
 
 #ifndef GTE_HOT_ONLY
