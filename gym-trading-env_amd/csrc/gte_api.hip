@@ -54,6 +54,7 @@ struct StateSoA {
 };
 hipError_t launch_extract_state(const EnvRec* rec, int n, const StateSoA& o, hipStream_t stream);
 hipError_t launch_rewind_queue(EnvRec* rec, int n, hipStream_t stream);
+hipError_t launch_forget_prices(EnvRec* rec, int n, hipStream_t stream);
 hipError_t launch_log(const EnvRec* rec, const double* reward64, const uint8_t* term,
                       const uint8_t* trunc, int n, int64_t row_base, const LogArrays& o,
                       hipStream_t stream);
@@ -572,6 +573,13 @@ int gte_upload_dataset(gte_env* E, int32_t d, const float* feat, const double* c
   for (int k = 0; k < 4; ++k) {
     if (E->ds_allocs[k][d]) (void)hipFree(E->ds_allocs[k][d]);
     E->ds_allocs[k][d] = dev[k];
+  }
+  E->p.ds0 = E->h_ds[0];  // the kernels' by-value copy of descriptor 0 (used when D == 1)
+  if (E->was_reset) {
+    // running envs keep the two prices of their next step in their records (EnvRec.px_*): values
+    // of the table that has just been replaced.  Forget them; the next step reads the new table.
+    HIPCHK(gte::launch_forget_prices(E->p.rec, p.N, E->stream));
+    HIPCHK(hipStreamSynchronize(E->stream));
   }
   return GTE_OK;
 }
