@@ -26,8 +26,6 @@ hipError_t launch_reset(const Params& p, int vec, int nt, bool coop, int stage, 
 size_t lds_bytes(const Params& p, int stage);
 hipError_t launch_step_hot(const Params& p, int blocks, int threads, size_t smem, hipStream_t stream);
 hipError_t launch_step_hot_nt(const Params& p, int blocks, int threads, size_t smem, hipStream_t stream);
-hipError_t launch_step5(const Params& p, int blocks, hipStream_t stream);
-hipError_t launch_step5_nt(const Params& p, int blocks, hipStream_t stream);
 int hot_blocks_per_cu(size_t smem);
 int hot_blocks_per_cu_nt(size_t smem);
 struct RolloutArgs {  // mirrors gte_rollout.hip
@@ -54,7 +52,6 @@ struct StateSoA {
 };
 hipError_t launch_extract_state(const EnvRec* rec, int n, const StateSoA& o, hipStream_t stream);
 hipError_t launch_rewind_queue(EnvRec* rec, int n, hipStream_t stream);
-hipError_t launch_forget_prices(EnvRec* rec, int n, hipStream_t stream);
 hipError_t launch_log(const EnvRec* rec, const double* reward64, const uint8_t* term,
                       const uint8_t* trunc, int n, int64_t row_base, const LogArrays& o,
                       hipStream_t stream);
@@ -462,6 +459,7 @@ int gte_create(const gte_config* cfg, gte_env** out) {
                  ? (p.persist ? 2 : 1) : 0;
   // the lean copy loop (gte_kernels.hip): 16-byte vectors with the raw rings staged in LDS
   p.lean_rows = (E->vec == 4 && E->stage == 1 && !p.persist && !(cfg->kernel_variant & 4096)) ? 1 : 0;
+  p.hot_lds = (cfg->kernel_variant & 8192) ? 0 : 1;  // (8192: A/B, the stepping lane stores its record itself)
   const int64_t waves = ((int64_t)p.N + epw - 1) / epw;
   E->threads = 64 * GTE_WAVES;
   E->blocks = (int)((waves + GTE_WAVES - 1) / GTE_WAVES);
@@ -573,13 +571,6 @@ int gte_upload_dataset(gte_env* E, int32_t d, const float* feat, const double* c
   for (int k = 0; k < 4; ++k) {
     if (E->ds_allocs[k][d]) (void)hipFree(E->ds_allocs[k][d]);
     E->ds_allocs[k][d] = dev[k];
-  }
-  E->p.ds0 = E->h_ds[0];  // the kernels' by-value copy of descriptor 0 (used when D == 1)
-  if (E->was_reset) {
-    // running envs keep the two prices of their next step in their records (EnvRec.px_*): values
-    // of the table that has just been replaced.  Forget them; the next step reads the new table.
-    HIPCHK(gte::launch_forget_prices(E->p.rec, p.N, E->stream));
-    HIPCHK(hipStreamSynchronize(E->stream));
   }
   return GTE_OK;
 }
@@ -790,17 +781,7 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
   // (hot_tu_covers: the isolated instantiations have no terminal records and no trajectory row)
   const bool hot = E->vec == 4 && E->coop && E->stage == 1 && !(E->cfg.kernel_variant & 64) &&
                    gte::hot_tu_covers(p);
-  // the decoupled 5-wave kernel (phase A beside the predicted copies): the lean copy loop's shapes,
-  // whole workgroups only; kernel_variant 8192 keeps the 4-wave kernel
-  const int64_t vpe5 = (int64_t)p.W * p.Fobs / 4;
-  const bool step5 = hot && p.lean_rows && GTE_WAVES == 4 && !(E->cfg.kernel_variant & 8192) && !(p.debug & ~112) &&
-                     p.N % (p.epw * 4) == 0 && vpe5 >= 64 && (p.epw * vpe5) % 256 == 0 &&
-                     (int64_t)p.epw * p.W <= 512;
-  if (step5 && E->cfg.nontemporal_obs == 2)
-    HIPCHK(gte::launch_step5(p, p.N / (p.epw * 4), E->stream));
-  else if (step5 && E->cfg.nontemporal_obs == 1)
-    HIPCHK(gte::launch_step5_nt(p, p.N / (p.epw * 4), E->stream));
-  else if (hot && E->cfg.nontemporal_obs == 2)
+  if (hot && E->cfg.nontemporal_obs == 2)
     HIPCHK(gte::launch_step_hot(p, E->blocks, E->threads, gte::lds_bytes(p, E->stage), E->stream));
   else if (hot && E->cfg.nontemporal_obs == 1)
     HIPCHK(gte::launch_step_hot_nt(p, E->blocks, E->threads, gte::lds_bytes(p, E->stage), E->stream));

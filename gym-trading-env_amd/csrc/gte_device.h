@@ -7,6 +7,7 @@
 // with -ffp-contract=off: an FMA would change roundings and break the
 // bit-exact agreement of the portfolio state with CPython.
 #pragma once
+#include <cstddef>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,24 +19,6 @@
 // only (tools/waves_ab.sh): the rollout kernels assume 4.
 #ifndef GTE_WAVES
 #define GTE_WAVES 4
-#endif
-
-// Round-3 experiment switches (A/B builds: make EXP="-DGTE_EXP_...=0|1"; tools/lib_ab.py): each
-// moves something off the head of phase A's dependency chain.  The defaults are the product.
-//   GTE_EXP_PRICE_CACHE  the next step's two prices and the dataset's row count travel in EnvRec
-//   GTE_EXP_DS0          descriptor 0 in the kernel arguments (no descriptor load with one dataset)
-//   GTE_EXP_POS_LDS      positions[] looked up in an LDS copy instead of global memory
-#ifndef GTE_EXP_PRICE_CACHE
-#define GTE_EXP_PRICE_CACHE 1
-#endif
-#ifndef GTE_EXP_NOSTORE
-#define GTE_EXP_NOSTORE 0  // timing probe: phase A's per-step global stores compiled out (results wrong)
-#endif
-#ifndef GTE_EXP_DS0
-#define GTE_EXP_DS0 1
-#endif
-#ifndef GTE_EXP_POS_LDS
-#define GTE_EXP_POS_LDS 1
 #endif
 
 namespace gte {
@@ -52,21 +35,18 @@ struct DatasetDesc {
 // through the L2-affinity permutation costs one line in and one line out (as a
 // struct of arrays the same gather touched 13 sectors per env and cancelled the
 // gain).  gte_get_state extracts struct-of-arrays views for the host on demand.
-//
-// The last 32 bytes cache what the NEXT step would otherwise fetch through two dependent loads
-// (descriptor -> price) at the head of its fp64 chain: a step trades at close[idx] — the price the
-// previous step valued the portfolio at — and values at close[idx + 1], which the previous step
-// asks for after its own arithmetic (its latency hides behind the gather).  px_key = idx + 1 of
-// the row the two prices belong to (0 = nothing cached: zero-filled records, after an upload);
-// the values are a pure function of (dataset, row), so a key match is all a reader needs.
-// ds_T = rows of the env's dataset (the truncation rule, environments.py:248).
 struct alignas(128) EnvRec {
-  int32_t idx, step, pos, dsi, start, episode, needs_reset, eps_on_ds;  // 32 B
-  int32_t n_picks, q_head, lo_n, ds_T;                                  // 16 B
-  double asset, fiat, ia, ifi, pv, realpos;                             // 48 B
-  double px_cur, px_next;                                               // 16 B close[row], close[row + 1]
-  int32_t px_key, px_dsi, pad1[2];                                      // 16 B -> 128 B
+  // hot half: what every step rewrites — ONE aligned 64-byte piece, which the step kernel writes as one
+  // request per env (through LDS: four lanes per env); as five scattered stores from the lane that
+  // stepped the env it was half of what phase A's stores cost (profiles/r03_step5_decoupled.log)
+  int32_t idx, step, pos, dsi;               // 16 B
+  double asset, fiat, ia, ifi, pv, realpos;  // 48 B
+  // cold half: written where it changes (a reset, a limit-order fill, an episode end)
+  int32_t start, episode, needs_reset, eps_on_ds;
+  int32_t n_picks, q_head, lo_n, pad0;
+  int32_t pad1[8];                           // -> 128 B
 };
+static_assert(offsetof(EnvRec, start) == 64, "EnvRec: the hot half is the first 64 bytes");
 static_assert(sizeof(EnvRec) == 128, "EnvRec must be one 128-byte line");
 
 // Trajectory log (optional, gte_config.log_steps): [L, N] arrays, one row per env after every
@@ -90,8 +70,6 @@ struct Params {
   int64_t env_id_base;
   // --- resident tables
   const DatasetDesc* ds;
-  DatasetDesc ds0;          // == ds[0], in the kernel arguments: with ONE dataset (configs 2-4) no
-                            // lane loads a descriptor (host copy kept current by gte_upload_dataset)
   const double* positions;  // f64 [P]
   // --- per-env state, one 128-byte record per env
   EnvRec* rec;
@@ -123,6 +101,7 @@ struct Params {
   int32_t epw;         // environments per wavefront
   int32_t debug;       // gte_config.debug_flags (timing ablations)
   int32_t lean_rows;   // != 0: full waves of 16-byte-vector windows take the lean copy loop (gte_kernels.hip)
+  int32_t hot_lds;     // != 0: a step's record stores go through LDS, one 64-byte request per env (gte_kernel)
   // --- trajectory row written by THIS launch's phase A (a gte_step with log_steps > 0; the
   // shared-TU step kernel only).  log.idx == null: none (the host appends it with gte_log_kernel)
   LogArrays log;

@@ -29,19 +29,6 @@ hipError_t GTE_HOT_NAME(launch_step_hot)(const Params& p, int blocks, int thread
   return hipGetLastError();
 }
 
-// The decoupled 5-wave kernel (gte_step5_kernel): 4 * epw envs per workgroup of 320 threads.
-hipError_t GTE_HOT_NAME(launch_step5)(const Params& p, int blocks, hipStream_t stream) {
-  if (!hot_tu_covers(p)) return hipErrorInvalidValue;  // features compiled out of this TU (gte_device.h)
-  const uint32_t V = (uint32_t)(p.W * p.Fobs);
-  auto magic = [](uint32_t d) { return ((1ull << 40) + d - 1) / d; };
-  const uint64_t vm = magic(V / 4), fm = magic((uint32_t)p.Fobs / 4),
-                 wm = magic((uint32_t)(p.W * (p.nd ? p.nd : 1)));
-  const int EPB = p.epw * 4;
-  const size_t smem = lds_bytes_classic(p, EPB) + (size_t)EPB * (sizeof(JobRec) + 4 * GTE_MAX_DYN);
-  hipLaunchKernelGGL((gte_step5_kernel<GTE_HOT_NT>), dim3(blocks), dim3(320), smem, stream, p, vm, fm, wm);
-  return hipGetLastError();
-}
-
 // Workgroups of this kernel one CU holds at once (registers, LDS): the launch geometry sizes
 // the workgroups so that all of them are resident together (gte_api.hip, choose_epw).
 int GTE_HOT_NAME(hot_blocks_per_cu)(size_t smem) {

@@ -68,82 +68,52 @@ enum { MODE_STEP = 0, MODE_RESET = 1 };
 // (episode, eps_on_ds, n_picks, q_head) stay in the record and are read / written there, inside
 // the rare reset branches: carried through the fp64 state machine they cost the step kernel
 // four more VGPRs, i.e. an occupancy step.
-// A pointer that was itself LOADED (a dataset descriptor's members) or that travelled through LDS
-// as an integer (the window's source) is a generic pointer to the compiler: it emits flat_load,
-// and flat loads count on vmcnt AND lgkmcnt — every LDS wait behind one, the workgroup barrier's
-// included, then waits for global memory.  Cast back to the global address space explicitly.
-template <typename T>
-__device__ inline T load_global(uint64_t base, int64_t index) {
-  typedef const T __attribute__((address_space(1))) * gptr_t;
-  return ((gptr_t)base)[index];
-}
-
 struct EnvRegs {
-  int32_t idx, step, pos, dsi, start, needs_reset, lo_n, ds_T;
+  int32_t idx, step, pos, dsi, start, needs_reset, lo_n;
   Portfolio q;
   double pv, realpos;
 };
 
-// The two prices a step needs, known one step ahead (EnvRec.px_*; a fused rollout keeps them in
-// registers): cur = close[idx], next = close[idx + 1] of dataset dsi.  idx < 0: nothing known.
-struct PriceCarry {
-  double cur, next;
-  int32_t idx, dsi;
-};
-
-__device__ inline void load_state(const Params& p, int e, EnvRegs& s, PriceCarry* pc = nullptr) {
-  const EnvRec* r = &p.rec[e];  // 128-byte aligned record: eight 16-byte loads, one line
+__device__ inline void load_state(const Params& p, int e, EnvRegs& s) {
+  const EnvRec* r = &p.rec[e];  // 128-byte aligned record: six 16-byte loads
   const int4* ri = reinterpret_cast<const int4*>(r);
   const int4 a = ri[0];  // idx, step, pos, dsi
-  const int4 b = ri[1];  // start, (episode), needs_reset, (eps_on_ds)
-  const int4 c = ri[2];  // (n_picks), (q_head), lo_n, ds_T
-  s.idx = a.x; s.step = a.y; s.pos = a.z; s.dsi = a.w;
-  s.start = b.x; s.needs_reset = b.z; s.lo_n = c.z; s.ds_T = c.w;
-  const double2* rd = reinterpret_cast<const double2*>(&r->asset);  // offset 48
+  const double2* rd = reinterpret_cast<const double2*>(&r->asset);  // offset 16
   const double2 d0 = rd[0], d1 = rd[1], d2 = rd[2];
+  const int4 b = ri[4];  // start, (episode), needs_reset, (eps_on_ds)
+  const int4 c = ri[5];  // (n_picks), (q_head), lo_n, pad
+  s.idx = a.x; s.step = a.y; s.pos = a.z; s.dsi = a.w;
+  s.start = b.x; s.needs_reset = b.z; s.lo_n = c.z;
   s.q.asset = d0.x; s.q.fiat = d0.y; s.q.ia = d1.x; s.q.ifi = d1.y;
   s.pv = d2.x; s.realpos = d2.y;
-  if (pc) {
-    const double2 px = rd[3];  // px_cur, px_next
-    const int4 k = ri[7];      // px_key, px_dsi
-    pc->cur = px.x; pc->next = px.y; pc->idx = k.x - 1; pc->dsi = k.y;
-  }
 }
 
-// start, lo_n and ds_T are written where they change (do_reset, fill_limit_orders, phase_a)
+// The record's hot half (EnvRec).  start, lo_n and needs_reset are written where they change
+// (do_reset, fill_limit_orders, the episode end in phase_a).
 __device__ inline void store_state_at(EnvRec* r, const EnvRegs& s) {
   *reinterpret_cast<int4*>(&r->idx) = make_int4(s.idx, s.step, s.pos, s.dsi);
-  r->needs_reset = s.needs_reset;
   double2* d = reinterpret_cast<double2*>(&r->asset);
   d[0] = make_double2(s.q.asset, s.q.fiat);
   d[1] = make_double2(s.q.ia, s.q.ifi);
   d[2] = make_double2(s.pv, s.realpos);
 }
+// The same 64 bytes into the workgroup's LDS image (slot = env of the workgroup): the gather waves
+// write them out, four lanes per env (flush_hot_records).  The pointer keeps its address space in its
+// type (as a generic pointer these would be flat stores).
+typedef int __attribute__((ext_vector_type(4))) int4_t;
+typedef double __attribute__((ext_vector_type(2))) double2_t;
+typedef unsigned char __attribute__((address_space(3))) * lds_byte_ptr;
+__device__ inline void store_state_lds(lds_byte_ptr h, const EnvRegs& s) {
+  typedef int4_t __attribute__((address_space(3))) * li4;
+  typedef double2_t __attribute__((address_space(3))) * ld2;
+  int4_t a = {s.idx, s.step, s.pos, s.dsi};
+  double2_t d0 = {s.q.asset, s.q.fiat}, d1 = {s.q.ia, s.q.ifi}, d2 = {s.pv, s.realpos};
+  *(li4)h = a;
+  *(ld2)(h + 16) = d0;
+  *(ld2)(h + 32) = d1;
+  *(ld2)(h + 48) = d2;
+}
 __device__ inline void store_state(const Params& p, int e, const EnvRegs& s) { store_state_at(&p.rec[e], s); }
-
-__device__ inline void store_prices(EnvRec* r, const PriceCarry& c) {
-  *reinterpret_cast<double2*>(&r->px_cur) = make_double2(c.cur, c.next);
-  *reinterpret_cast<int2*>(&r->px_key) = make_int2(c.idx + 1, c.dsi);
-}
-
-// feature table / close column of dataset dsi: kernel arguments with one dataset, else two
-// loads from its descriptor
-__device__ inline void dataset_pointers(const Params& p, int32_t dsi, const float*& feat,
-                                        const double*& close) {
-  if (GTE_EXP_DS0 && p.D == 1) { feat = p.ds0.feat; close = p.ds0.close; return; }  // wave-uniform
-  const DatasetDesc* dp = p.ds + dsi;
-  feat = dp->feat; close = dp->close;
-}
-
-// positions[i]: from the workgroup's LDS copy when the caller staged one (no global load behind
-// the record load on the step's dependency chain), else from the table in global memory.  The LDS
-// pointer keeps its address space in its TYPE: as a generic pointer the two sources merge into one
-// flat_load (which ties up both vmcnt and lgkmcnt).
-typedef const double __attribute__((address_space(3))) * lds_f64_ptr;
-__device__ inline double position_value(const Params& p, lds_f64_ptr pos_lds, int32_t i) {
-  if (pos_lds) return pos_lds[i];
-  return p.positions[i];
-}
 
 // MultiDatasetTradingEnv.next_dataset, environments.py:380-391
 __device__ inline void next_dataset(const Params& p, int e, int32_t inj_ds, EnvRegs& s,
@@ -158,7 +128,7 @@ __device__ inline void next_dataset(const Params& p, int e, int32_t inj_ds, EnvR
 
 // TradingEnv.reset, environments.py:163-199 (+ MultiDataset reset :393-400)
 __device__ inline void do_reset(const Params& p, int e, int32_t inj_idx, int32_t inj_pos,
-                                int32_t inj_ds, EnvRegs& s, bool& fresh, PriceCarry& pc) {
+                                int32_t inj_ds, EnvRegs& s, bool& fresh) {
   EnvRec* rec = &p.rec[e];
   if (p.D > 1) {  // :394-398
     const int32_t eps = rec->eps_on_ds + 1;
@@ -185,13 +155,8 @@ __device__ inline void do_reset(const Params& p, int e, int32_t inj_idx, int32_t
   s.start = idx;
   rec->start = idx;
   rec->lo_n = 0;
-  s.ds_T = (int32_t)d.T;
-  rec->ds_T = s.ds_T;
   const double position = p.positions[pi];  // TargetPortfolio, portfolio.py:59-66
-  const double price = load_global<double>((uint64_t)d.close, idx);
-  // the first step of the episode trades at this price and values at the next row's (idx <= T - 2:
-  // gte_upload_dataset / check_injection)
-  pc.cur = price; pc.next = load_global<double>((uint64_t)d.close, idx + 1); pc.idx = idx; pc.dsi = s.dsi;
+  const double price = d.close[idx];
   s.q.asset = position * p.V0 / price;
   s.q.fiat = (1.0 - position) * p.V0;
   s.q.ia = 0.0;
@@ -199,6 +164,7 @@ __device__ inline void do_reset(const Params& p, int e, int32_t inj_idx, int32_t
   s.pv = p.V0;          // :194
   s.realpos = position; // :192
   s.needs_reset = 0;
+  rec->needs_reset = 0;
 }
 
 // TradingEnv._take_action_order_limit, environments.py:217-223: every pending order
@@ -273,21 +239,21 @@ __device__ inline void pop_injection(const Params& p, int e, EnvRegs& s, int32_t
 // Dynamic features of the current row (:153-154) -> the env's store, and the
 // description of the window copy for phase B.
 __device__ inline void make_job(const Params& p, int e, const EnvRegs& s, bool fresh,
-                                ObsJob& job, const float* feat, double position) {
+                                ObsJob& job) {
 #pragma unroll
   for (int i = 0; i < GTE_MAX_DYN; ++i) {
     float v = 0.0f;
     if (i < p.nd) {
       const double x = (p.dyn_kind[i] == GTE_DYN_REAL_POSITION) ? s.realpos   // :23-24
-                                                                : position;  // :20-21 positions[s.pos]
+                                                                : p.positions[s.pos];  // :20-21
       v = (float)x;
       const int64_t slot = p.persist ? (int64_t)s.idx : (int64_t)(s.idx % p.W);
-      if (!(GTE_EXP_NOSTORE & 4)) p.ring[((int64_t)e * p.depth + slot) * p.nd + i] = v;
+      p.ring[((int64_t)e * p.depth + slot) * p.nd + i] = v;
     }
     job.cur[i] = v;
   }
   const int32_t first = s.idx - p.W + 1;  // first row of the window (:159)
-  job.src = feat + (int64_t)first * p.Fobs;
+  job.src = p.ds[s.dsi].feat + (int64_t)first * p.Fobs;
   job.slot0 = p.persist ? first : (s.idx + 1) % p.W;
   int32_t nz;
   if (fresh) nz = p.W - 1;            // brand-new _obs_array: only the current row is set
@@ -304,6 +270,10 @@ __device__ inline void make_job(const Params& p, int e, const EnvRegs& s, bool f
 // ---------------------------------------------------------------------------
 // phase A
 
+// Prices a fused rollout carries from step to step (one lane = one env): a step trades at
+// close[idx] — the price the previous step valued the portfolio at — and values at close[idx+1],
+// which the previous step already asked for; the load that would head every step's dependency
+// chain is issued a step early instead.  Invalid (idx < 0) after anything but a plain step.
 // What a step returned for one env, for a caller that also writes the trajectory row.
 struct StepOut {
   double reward, pv, realpos, asset, fiat, ia, ifi;  // reward of the step; the rest: state after it
@@ -311,23 +281,23 @@ struct StepOut {
   int32_t flags;  // bit0 terminated, bit1 truncated
 };
 
+struct PriceCarry {
+  double cur, next;  // close[idx], close[idx + 1] of dataset dsi
+  int32_t idx, dsi;
+};
+
 // compact: add the envs whose episode ended to the terminal list (off for the inner steps
 // of a fused rollout, which keeps per-step flags instead); pv_out: the valuation after the step.
 // carried: the env's registers live across calls (the fused rollout keeps them there for all K
 // steps: no record load per step; the record is still written through); action_in: the action
 // was loaded ahead of time.  Both are nullptr — and fold away — in the per-step kernels.
-// pc: the prices known one step ahead (PriceCarry) — a fused rollout's registers; nullptr: read
-// from / written back to the env's record.  pos_lds: the workgroup's LDS copy of `positions`, or
-// nullptr.
-// CARRY: `carried` is given (a template argument, not a null test: a null test of a pointer to a
-// private object does not fold, and the object then stays in scratch).
-template <int MODE, bool CARRY = false>
+template <int MODE>
 __device__ inline void phase_a(const Params& p, int e, bool active, int lane, ObsJob& job,
                                FinalJob* fin = nullptr, bool compact = true,
                                double* pv_out = nullptr, EnvRegs* carried = nullptr,
                                const int32_t* action_in = nullptr, bool write_record = true,
                                PriceCarry* pc = nullptr, StepOut* so = nullptr,
-                               lds_f64_ptr pos_lds = nullptr) {
+                               lds_byte_ptr hot = nullptr) {
   // write_record = false (fused rollouts, with `carried`): the record is not written through on
   // this step — the caller stores it once, after its last step (fields a reset or a limit-order
   // fill changes are written where they change, whatever this flag says)
@@ -340,21 +310,17 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
   if (MODE == MODE_RESET) {
     if (active && (p.mask == nullptr || p.mask[e] != 0)) {
       EnvRegs s;
-      PriceCarry c;
       load_state(p, e, s);
       bool fresh = false;
       const int32_t ii = p.inj_idx ? p.inj_idx[e] : -1;
       const int32_t ip = p.inj_pos ? p.inj_pos[e] : -1;
       const int32_t id = p.inj_ds ? p.inj_ds[e] : -1;
       if (p.D > 1 && p.rec[e].n_picks == 0) next_dataset(p, e, id, s, fresh);  // ctor pick, :378
-      do_reset(p, e, ii, ip, id, s, fresh, c);
+      do_reset(p, e, ii, ip, id, s, fresh);
       store_state(p, e, s);
-      store_prices(&p.rec[e], c);
       p.reward[e] = 0.0f; p.reward64[e] = 0.0;
       p.terminated[e] = 0; p.truncated[e] = 0;
-      const float* feat; const double* close;
-      dataset_pointers(p, s.dsi, feat, close);
-      make_job(p, e, s, fresh, job, feat, p.positions[s.pos]);
+      make_job(p, e, s, fresh, job);
     }
     return;
   }
@@ -362,37 +328,21 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
   // MODE_STEP — TradingEnv.step, environments.py:233-272
   if (active) {
     EnvRegs s_own;
-    EnvRegs& s = CARRY ? *carried : s_own;
-    PriceCarry c_own = {0.0, 0.0, -1, 0};
-    PriceCarry& c = pc ? *pc : c_own;
-    if (!CARRY) load_state(p, e, s, (pc || !GTE_EXP_PRICE_CACHE) ? nullptr : &c);
+    EnvRegs& s = carried ? *carried : s_own;
+    if (!carried) load_state(p, e, s);
     int32_t action = action_in ? *action_in : p.actions[e];
     GTE_STAMP(2);  // record + action arrived
     // positions[position_index] raises IndexError in the reference (:234); a device-side
     // action cannot raise, so an out-of-range index is treated as None (hold), never read
     if (action >= p.P) action = -1;
-    // The dataset's feature table / close column: kernel arguments with one dataset, else two
-    // loads issued NOW, whose latency the fp64 arithmetic below covers (the gather's source pointer
-    // and the address of the price asked for after it)
-    // (a fused rollout — `carried` — fetches them where they are used instead: its registers are
-    // the scarce resource, and it runs a step ahead of its gather anyway)
-    const int32_t dsi0 = s.dsi;
-    const float* feat0 = nullptr;
-    const double* close0 = nullptr;
-    if (!CARRY) dataset_pointers(p, dsi0, feat0, close0);
-    auto feat_of = [&](int32_t dsi) -> const float* {  // feature table of the env's dataset NOW
-      if (!CARRY && dsi == dsi0) return feat0;
-      const float* f; const double* unused;
-      dataset_pointers(p, dsi, f, unused);
-      return f;
-    };
     bool fresh = false;
     bool stepped = true;
     if (s.needs_reset) {
       if (p.autoreset == GTE_AUTORESET_NEXT_STEP) {
         int32_t qi, qp, qd;
         pop_injection(p, e, s, qi, qp, qd);
-        do_reset(p, e, qi, qp, qd, s, fresh, c);
+        do_reset(p, e, qi, qp, qd, s, fresh);
+        if (pc) pc->idx = -1;
         p.reward[e] = 0.0f; p.reward64[e] = 0.0;
         p.terminated[e] = 0; p.truncated[e] = 0;
         if (so) { so->reward = 0.0; so->flags = 0; }
@@ -412,47 +362,30 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
       }
     }
     if (stepped) {
-      if (c.idx != s.idx || c.dsi != s.dsi) {
-        // nothing cached for this row (a zero-filled record, the first step after an upload): the
-        // descriptor -> price loads every step used to start with
-        const DatasetDesc* dp = p.ds + s.dsi;
-        const int32_t T = (int32_t)dp->T;
-        if (s.ds_T != T) p.rec[e].ds_T = T;
-        s.ds_T = T;
-        const uint64_t cl = (uint64_t)dp->close;
-        c.cur = load_global<double>(cl, s.idx);
-        c.next = load_global<double>(cl, s.idx + 1 < T ? s.idx + 1 : s.idx);
-        c.idx = s.idx; c.dsi = s.dsi;
-      }
-      const int32_t d_T = s.ds_T;
-      // The price the step AFTER the next one values at, close[idx + 2], asked for NOW: its address
-      // needs nothing but the record, and the fp64 arithmetic below covers its latency, so that it
-      // can be stored with the record before the barrier.  (Asked for after the arithmetic and
-      // stored behind the barrier, wave 0's two scattered stores landed in the middle of the
-      // other waves' copy traffic: 48.9 us per step instead of 40.8, profiles/r03_price_cache_ab.log.)
-      const bool ahead = (GTE_EXP_PRICE_CACHE || pc) && s.idx + 2 < d_T;
-      double px_ahead = 0.0;
-      if (ahead) {
-        const double* cl = close0;
-        if (CARRY) { const float* unused; dataset_pointers(p, s.dsi, unused, cl); }
-        px_ahead = load_global<double>((uint64_t)cl, s.idx + 2);
-      }
+      // only the fields this path needs (the whole 40-byte descriptor held in registers
+      // across the fp64 state machine costs the kernel an occupancy step)
+      const DatasetDesc* dp = p.ds + s.dsi;
+      const double* d_close = dp->close;
+      const int32_t d_T = (int32_t)dp->T;
+      const bool carried_prices = pc && pc->idx == s.idx && pc->dsi == s.dsi;
       if (action >= 0) {  // :234 -> :213-215: trade only when the position VALUE differs
-        const double position = position_value(p, pos_lds, action);
-        if (position != position_value(p, pos_lds, s.pos)) {
-          trade_to_position(s.q, position, c.cur, p.fees);  // :204-209, at close[idx]
-          s.pos = action;                                    // :210
+        const double position = p.positions[action];
+        if (position != p.positions[s.pos]) {
+          trade_to_position(s.q, position, carried_prices ? pc->cur : d_close[s.idx], p.fees);  // :204-209
+          s.pos = action;                                            // :210
         }
       }
       s.idx += 1;   // :235
       s.step += 1;  // :236
-      if (p.lo_pos) fill_limit_orders(p, e, p.ds + s.dsi, s);  // :238
-      const double price = c.next;  // :239 close[idx] at the new row
-      // this step's valuation price is the next step's trade price; the one after was asked for above
-      c.cur = price;
-      c.idx = s.idx;
-      c.next = ahead ? px_ahead : price;
-      GTE_STAMP(3);  // positions, trade, prices: nothing arrived from memory since stamp 2
+      if (p.lo_pos) fill_limit_orders(p, e, dp, s);  // :238
+      const double price = carried_prices ? pc->next : d_close[s.idx];  // :239
+      if (pc) {  // this step's valuation price is the next step's trade price; ask for the one after
+        pc->cur = price;
+        pc->idx = s.idx;
+        pc->dsi = s.dsi;
+        pc->next = (s.idx + 1 < d_T) ? d_close[s.idx + 1] : price;
+      }
+      GTE_STAMP(3);  // descriptor, positions, trade, price at the new row arrived
       s.q.ia = pymax0(-s.q.asset) * p.rate;   // update_interest, portfolio.py:44-46
       s.q.ifi = pymax0(-s.q.fiat) * p.rate;
       const double pv = valorisation(s.q, price);  // :241
@@ -463,29 +396,29 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
       double rew = 0.0;                            // :263, stays 0 when done (:265)
       if (!done) rew = reward_of(p, pv, s.pv);
       s.pv = pv;
-#if !(GTE_EXP_NOSTORE & 2)
       p.reward64[e] = rew;
       p.reward[e] = (float)rew;
       p.terminated[e] = done ? 1 : 0;
       p.truncated[e] = trunc ? 1 : 0;
-#endif
       if (so) { so->reward = rew; so->flags = (done ? 1 : 0) | (trunc ? 2 : 0); }
       ended = done || trunc;
-      if (ended) s.needs_reset = 1;
+      if (ended) { s.needs_reset = 1; p.rec[e].needs_reset = 1; }
       if (ended && p.autoreset == GTE_AUTORESET_SAME_STEP) {
         // the reference's step() runs _get_obs (:272) before any wrapper resets the env:
         // write the terminal row's dynamic features, remember the terminal window
 #ifndef GTE_HOT_ONLY  // p.final_rec: hot_tu_covers() keeps such launches off the isolated TUs
         if (p.final_rec) {  // what the wrapper's `final_info` reports (state before the reset)
           store_state_at(&p.final_rec[e], s);
+          p.final_rec[e].needs_reset = s.needs_reset;
           p.final_rec[e].start = s.start;
         }
 #endif
         ObsJob term;
-        make_job(p, e, s, false, term, feat_of(s.dsi), position_value(p, pos_lds, s.pos));
+        make_job(p, e, s, false, term);
         int32_t qi, qp, qd;
         pop_injection(p, e, s, qi, qp, qd);
-        do_reset(p, e, qi, qp, qd, s, fresh, c);
+        do_reset(p, e, qi, qp, qd, s, fresh);
+        if (pc) pc->idx = -1;
         if (fin && p.final_obs) {
           fin->src = term.src; fin->slot0 = term.slot0; fin->n_zero = term.n_zero; fin->flags = 1;
           // the reset's current row is about to overwrite one ring slot the terminal window
@@ -502,17 +435,16 @@ __device__ inline void phase_a(const Params& p, int e, bool active, int lane, Ob
     }
     GTE_STAMP(4);  // state machine done, outputs issued
     if (pv_out) *pv_out = s.pv;
-    if (write_record && !(GTE_EXP_NOSTORE & 1)) {
-      store_state(p, e, s);
-      if ((GTE_EXP_PRICE_CACHE || pc) && c.idx >= 0) store_prices(&p.rec[e], c);
+    if (write_record) {
+      if (hot) store_state_lds(hot, s);  // (written out by the gather waves: flush_hot_records)
+      else store_state(p, e, s);
     }
     if (so) {
       so->idx = s.idx; so->step = s.step; so->pos = s.pos; so->dsi = s.dsi;
       so->pv = s.pv; so->realpos = s.realpos;
       so->asset = s.q.asset; so->fiat = s.q.fiat; so->ia = s.q.ia; so->ifi = s.q.ifi;
     }
-    // (feat_of: a reset may have moved the env to another dataset)
-    make_job(p, e, s, fresh, job, feat_of(s.dsi), position_value(p, pos_lds, s.pos));
+    make_job(p, e, s, fresh, job);
     GTE_STAMP(5);  // record, ring and job stores done
   }
 
@@ -564,6 +496,16 @@ __device__ inline void store_out(T* dst, const T& v) {
   }
 }
 
+// The window's source pointer travels through LDS as a 64-bit integer, which makes the
+// compiler forget that it points to global memory: it then emits flat_load, and flat
+// loads count on vmcnt AND lgkmcnt (every LDS read in the loop waits for them).  Cast
+// back to the global address space explicitly.
+template <typename T>
+__device__ inline T load_global(uint64_t base, int64_t index) {
+  typedef const T __attribute__((address_space(1))) * gptr_t;
+  return ((gptr_t)base)[index];
+}
+
 // Put nd dynamic values x[0..nd) into vector v, which is the LAST vector of a window row.
 // With 16-byte vectors F_obs % 4 == 0 and nd <= 4, so the dynamic columns are exactly the
 // last nd components of that vector: a wave-uniform switch, no per-component compares.
@@ -599,9 +541,9 @@ __device__ inline int meta_slot0(uint32_t m) { return (int)(m >> 17); }
 // workgroup) and, when staged, the dynamic-column values of every window row.
 struct WgLds {
   JobRec* job;      // [EPB]
+  unsigned char* hot;  // [EPB][64] the records' hot halves as phase A leaves them (flush_hot_records)
   int32_t* idx;     // [EPB] current row (persist mode's zero-fill needs it)
   float* cur;       // [EPB][GTE_MAX_DYN] dynamic features of the current row
-  double* pos;      // [GTE_MAX_POSITIONS] copy of p.positions (phase A looks positions up here)
   FinalJob* fin;    // [EPB] terminal windows (only when p.final_obs)
   float* staged;    // [EPB][W][nd]: the raw rings; the lean copy loop resolves a wave's part IN
                     // PLACE into window order (rotation / zero rows / current row applied)
@@ -609,24 +551,26 @@ struct WgLds {
 
 __device__ inline WgLds carve_lds(unsigned char* base, int EPB, bool with_final) {
   WgLds L;
-  // (offsets only, never an integer round trip: a pointer rebuilt from an integer loses its LDS
-  // address space, and every access through it — the staged rings in the copy loop — becomes a
-  // FLAT instruction: measured 52 us per step instead of 39)
   L.job = (JobRec*)base;                   base += 16 * EPB;
-  L.pos = (double*)base;                   base += 8 * GTE_MAX_POSITIONS;
-  L.fin = (FinalJob*)base;                 base += with_final ? sizeof(FinalJob) * EPB : 0;  // 8-byte aligned
+  L.hot = base;                            base += 64 * EPB;
   L.cur = (float*)base;                    base += 4 * GTE_MAX_DYN * EPB;
   L.idx = (int32_t*)base;                  base += 4 * EPB;
+  L.fin = (FinalJob*)base;                 base += with_final ? sizeof(FinalJob) * EPB : 0;
   L.staged = (float*)base;
   return L;
 }
 
-// bytes of the classic LDS image (jobs, current values, rows, raw rings) of a workgroup of EPB envs,
-// rounded up to 16: where the decoupled kernel's extra arrays start (device copy of lds_bytes())
-__device__ __host__ inline size_t lds_bytes_classic(const Params& p, int EPB) {
-  size_t b = (size_t)EPB * (16 + 4 * GTE_MAX_DYN + 4) + 8 * GTE_MAX_POSITIONS +
-             (size_t)EPB * (size_t)p.W * (size_t)(p.nd ? p.nd : 1) * 4;
-  return (b + 15) & ~(size_t)15;
+// The records' hot halves, from the LDS image phase A left (store_state_lds) to the records: four
+// lanes per env, i.e. one 64-byte request per env where the lane that stepped the env issued four
+// 16-byte stores to 64 different lines each.
+__device__ inline void flush_hot_records(const Params& p, const WgLds& L, int s_first, int n_env, int lane) {
+  typedef float __attribute__((ext_vector_type(4))) f4;
+  for (int i = lane; i < n_env * 4; i += 64) {  // (one pass with 16 envs per wave)
+    const int sl = s_first + (i >> 2), part = i & 3;
+    const int env = L.job[sl].env;  // (>= 0 for the first n_env slots)
+    const f4 v = *reinterpret_cast<const f4*>(L.hot + 64 * sl + 16 * part);
+    *(reinterpret_cast<f4*>(&p.rec[env]) + part) = v;
+  }
 }
 
 // phase A's lane publishes its env's job (the env id was written at kernel start)
@@ -1018,19 +962,10 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
     const bool owns = COOP ? (lane < EPB) : (lane < p.epw);
     const bool active = owns && s < n_wg;
     const int e = active ? (p.perm ? p.perm[wg_first + s] : wg_first + s) : 0;
-    // positions[] into LDS: the load is issued with the perm / record loads, and the state machine
-    // then looks positions up in LDS instead of waiting for a global load behind the record
-    // (LDS operations of one wave execute in order; every phase-A wave writes the same values)
-    lds_f64_ptr pos_lds = nullptr;
-    if (MODE == MODE_STEP && GTE_EXP_POS_LDS) {
-      if (lane < p.P) L.pos[lane] = p.positions[lane];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      pos_lds = (lds_f64_ptr)L.pos;
-    }
     ObsJob job;
     FinalJob fin;
+    // a step's record stores: into the LDS image (one 64-byte request per env after the barrier)
+    const lds_byte_ptr hot = (MODE == MODE_STEP && p.hot_lds) ? (lds_byte_ptr)(L.hot + 64 * s) : (lds_byte_ptr) nullptr;
 #ifndef GTE_HOT_ONLY  // p.log: hot_tu_covers() keeps such launches off the isolated TUs
     if (MODE == MODE_STEP && p.log.idx) {
       // gte_step with log_steps: the lane that stepped the env also writes its trajectory row —
@@ -1038,36 +973,29 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
       // second launch reading everything back (4.5 us per step)
       StepOut so = {};
       phase_a<MODE>(p, e, active, lane, job, p.final_obs ? &fin : nullptr, true, nullptr, nullptr, nullptr,
-                    true, nullptr, &so, pos_lds);
+                    true, nullptr, &so, hot);
       if (active) {
         const int64_t k = p.log_row_base + e;
         p.log.idx[k] = so.idx; p.log.step[k] = so.step; p.log.pos[k] = so.pos; p.log.dsi[k] = so.dsi;
-        p.log.pv[k] = so.pv; p.log.realpos[k] = so.realpos;
-        p.log.reward[k] = (so.step == 0) ? 0.0 : so.reward;  // reset rows: 0 (:196)
+        p.log.pv[k] = so.pv; p.log.realpos[k] = so.realpos; p.log.reward[k] = (so.step == 0) ? 0.0 : so.reward;  // reset rows: 0 (:196)
         p.log.asset[k] = so.asset; p.log.fiat[k] = so.fiat; p.log.ia[k] = so.ia; p.log.ifi[k] = so.ifi;
         p.log.flags[k] = (uint8_t)so.flags;
       }
     } else
 #endif
-    phase_a<MODE>(p, e, active, lane, job, p.final_obs ? &fin : nullptr, true, nullptr, nullptr, nullptr,
-                  true, nullptr, nullptr, pos_lds);
+    phase_a<MODE>(p, e, active, lane, job, p.final_obs ? &fin : nullptr, true, nullptr, nullptr, nullptr, true,
+                  nullptr, nullptr, hot);
     if (owns) publish_job(L, s, job);  // slots past the last env get flags = 0
     if (owns && p.final_obs) L.fin[s] = fin;
   }
   // Only LDS has to be visible across the barrier (jobs, env ids, staged rings): nothing
   // after it reads global memory written before it in this launch.  __syncthreads() would
   // also drain wave 0's global stores (record, outputs, ring: 2.5 us in the timeline).
-#if defined(GTE_EXP_DRAIN) && GTE_EXP_DRAIN
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (A/B: stores drained first)
-#else
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-#if defined(GTE_EXP_PAD) && GTE_EXP_PAD > 0  // (A/B: shifts the address of the copy loop, nothing else)
-  asm volatile(".rept %0\n\ts_nop 0\n\t.endr" ::"n"(GTE_EXP_PAD));
-#endif
   GTE_STAMP(6);
 
-  // ---- phase B: each wave gathers the windows of its own EPW envs
+  // ---- phase B: each wave writes out the records of its own EPW envs and gathers their windows
+  if (MODE == MODE_STEP && p.hot_lds && n_env > 0) flush_hot_records(p, L, s_first, n_env, lane);
   if (n_env <= 0 || (p.debug & 1)) return;
   if (p.persist) zero_fresh_stores(p, L, s_first, n_env, lane);
   if (STAGE == STAGE_LATE) {
@@ -1106,194 +1034,6 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
   if (!lean) phase_b<VEC, NT, STAGE, GTE_GATHER_U>(p, L, s_first, n_env, lane, vpe_magic, fv_magic);
   GTE_STAMP(7);
   if (MODE == MODE_STEP && p.final_obs) final_windows<VEC>(p, L, s_first, n_env, lane, fv_magic);
-}
-
-// ---------------------------------------------------------------------------
-// Decoupled step kernel (round 3): phase A and the copies of the SAME step run side by side.
-//
-// In gte_kernel every copy waits ~8 us for its workgroup's phase A (dispatch ramp + dependent
-// loads + the fp64 chain) while the store path — the resource the step is bound by — idles.  But
-// what phase A decides about an observation is almost nothing: a running env's window is rows
-// idx+1-W+1 .. idx+1 of its table — known from the record alone — with the dynamic columns of the
-// older rows in its ring; only the CURRENT row's dynamic values (one 16-byte vector) and the
-// rare reset / episode end depend on the step.  So: 5 wavefronts per workgroup.
-//   wave 0      phase A for the workgroup's 4*epw envs, exactly as in gte_kernel; it publishes the
-//               real jobs to LDS, then issues its global stores (it copies nothing, so the slow
-//               service its scattered stores get beside the copy traffic delays nobody);
-//   waves 1-4   each PREDICTS the jobs of its epw envs from their records, stages + resolves their
-//               rings and copies the predicted windows with the lean loop at once;
-//   barrier;    each copy wave compares real and predicted jobs (source row, zero rows, ring
-//               rotation): equal -> it only rewrites each env's last vector (the current row's
-//               dynamic values); different for any of its envs (a reset, an episode end in
-//               same-step mode, a frozen env) -> it redoes its envs from the real jobs.
-// Same results as gte_kernel bit for bit by construction: whatever was predicted is checked
-// against what phase A published, and every vector that could differ is rewritten.
-// Shapes: the lean loop's (16-byte vectors, raw rings in LDS, whole passes), N a multiple of the
-// workgroup's envs, no terminal records / in-kernel log / persist; gte_step falls back otherwise.
-template <int NT>
-__global__ __launch_bounds__(320) void gte_step5_kernel(const Params p, const uint64_t vpe_magic,
-                                                        const uint64_t fv_magic, const uint64_t wnd_magic) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char gte_smem[];
-  const int lane = threadIdx.x & 63;
-  const int wib = threadIdx.x >> 6;  // 0: phase A; 1..4: copy waves
-  if (blockIdx.x == 0 && threadIdx.x == 0) p.term_count_next[0] = 0;
-  const int EPB = p.epw * 4;
-  const int wg_first = blockIdx.x * EPB;  // (N % EPB == 0: the host checks)
-  const WgLds L = carve_lds(gte_smem, EPB, false);
-  // predicted jobs + a block of zeros standing in for the (unknown) current-row values
-  JobRec* pjob = (JobRec*)(gte_smem + lds_bytes_classic(p, EPB));
-  float* pcur = (float*)(pjob + EPB);
-  WgLds LP = L;
-  LP.job = pjob;
-  LP.cur = pcur;
-  const uint32_t W = (uint32_t)p.W, FV = (uint32_t)p.Fobs / 4u, VPE = W * FV, V = VPE * 4u;
-
-  if (wib == 0) {
-    // ---- phase A (lane = env of the workgroup).  Everything it needs from memory — the record with
-    // the two prices cached in it, the action, the positions table — is asked for first, with the
-    // memory system still idle; the copy waves start behind barrier #1, i.e. once it has all arrived,
-    // and from there on phase A is arithmetic and LDS only (its global stores, issued into the
-    // copy traffic, are waited for by nobody).
-    const int s = lane;
-    const bool active = s < EPB;
-    const int e = active ? (p.perm ? p.perm[wg_first + s] : wg_first + s) : 0;
-    if (lane < p.P) L.pos[lane] = p.positions[lane];
-    EnvRegs regs = {};
-    PriceCarry pc = {0.0, 0.0, -1, 0};
-    int32_t action = -1;
-    if (active) {
-      load_state(p, e, regs, &pc);
-      action = p.actions[e];
-    }
-    // barrier #1.  One operand out of every 16-byte load: the values are "rewritten" here, so nothing
-    // computed from them moves above, and the record stays in registers (a memory clobber put it in scratch)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // L.pos
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"
-                 : "+v"(regs.idx), "+v"(regs.start), "+v"(regs.lo_n), "+v"(regs.q.asset), "+v"(regs.q.ia),
-                   "+v"(regs.pv), "+v"(pc.cur), "+v"(pc.idx), "+v"(action));
-    ObsJob job;
-    phase_a<MODE_STEP, true>(p, e, active, lane, job, nullptr, true, nullptr, &regs, &action, true, &pc, nullptr,
-                       (lds_f64_ptr)L.pos);
-    if (active) publish_job(L, s, job);
-  } else {
-    // ---- copy wave: predict, stage, copy
-    const int s_first = (wib - 1) * p.epw;
-    const int n_env = p.epw;
-    int32_t e = 0;
-    if (lane < n_env) {
-      const int slot = wg_first + s_first + lane;
-      e = p.perm ? p.perm[slot] : slot;
-      L.job[s_first + lane].env = e;  // (publish_job leaves .env alone)
-      // the env's record: idx, dataset, start row, whether it is due a reset
-      const int4 a = reinterpret_cast<const int4*>(&p.rec[e])[0];  // idx, step, pos, dsi
-      const int4 b = reinterpret_cast<const int4*>(&p.rec[e])[1];  // start, episode, needs_reset, eps_on_ds
-      const DatasetDesc* dp = p.ds + a.w;
-      // :235 if the env just steps; an env due a next-step reset moves to a row only phase A knows
-      // (predict its present window: valid rows, and a zero-row count no real job has, so that it
-      // is redone), an env frozen on the last row stays where it is
-      const bool resets = b.z && p.autoreset == GTE_AUTORESET_NEXT_STEP;
-      const bool stays = b.z && (resets || a.x >= (int32_t)dp->T - 1);
-      const int32_t idx = stays ? a.x : a.x + 1;
-      const int32_t first = idx - (int32_t)W + 1;
-      int32_t nz = b.x - first;
-      nz = nz < 0 ? 0 : (nz > (int32_t)W - 1 ? (int32_t)W - 1 : nz);
-      JobRec j;
-      j.src = (uint64_t)(dp->feat + (int64_t)first * p.Fobs);
-      j.env = e;
-      j.meta = pack_meta(1, resets ? 0x7FFF : nz, (idx + 1) % (int32_t)W);
-      pjob[s_first + lane] = j;
-#pragma unroll
-      for (int i = 0; i < GTE_MAX_DYN; ++i) pcur[(s_first + lane) * GTE_MAX_DYN + i] = 0.0f;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    stage_raw_rings(p, LP, s_first, n_env, lane, wnd_magic);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier #1: phase A has its data
-    if (!(p.debug & 32)) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      switch (p.nd) {
-        case 1: resolve_dynamic_rows<1>(p, LP, s_first, n_env, lane, wnd_magic); break;
-        case 2: resolve_dynamic_rows<2>(p, LP, s_first, n_env, lane, wnd_magic); break;
-        case 3: resolve_dynamic_rows<3>(p, LP, s_first, n_env, lane, wnd_magic); break;
-        default: resolve_dynamic_rows<4>(p, LP, s_first, n_env, lane, wnd_magic); break;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      switch (p.nd) {
-        case 1: phase_b_lean<NT, 1>(p, LP, s_first, n_env, lane); break;
-        case 2: phase_b_lean<NT, 2>(p, LP, s_first, n_env, lane); break;
-        case 3: phase_b_lean<NT, 3>(p, LP, s_first, n_env, lane); break;
-        default: phase_b_lean<NT, 4>(p, LP, s_first, n_env, lane); break;
-      }
-    }
-  }
-  // real jobs (wave 0) and predicted copies (waves 1-4) are done; only LDS has to be visible
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  if (wib == 0) return;
-
-  // ---- fix-up
-  const int s_first = (wib - 1) * p.epw;
-  const int n_env = p.epw;
-  const int sl = s_first + (lane < n_env ? lane : 0);
-  const JobRec real = L.job[sl], pred = pjob[sl];
-  const bool same = real.src == pred.src && real.meta == pred.meta && (real.meta & 1u);
-  if (__ballot(lane < n_env && !same) == 0ull) {
-    // every prediction held: only the current row's dynamic values were unknown — the last vector
-    if (lane < n_env) {
-      float4_t v = load_global<float4_t>(real.src, (int64_t)(VPE - 1u));
-      float x[GTE_MAX_DYN];
-#pragma unroll
-      for (int i = 0; i < GTE_MAX_DYN; ++i) x[i] = L.cur[sl * GTE_MAX_DYN + i];
-      set_tail(v, p.nd, x);
-      store_out<NT>((float4_t*)(p.obs + (int64_t)real.env * V + (int64_t)(VPE - 1u) * 4), v);
-    }
-    return;
-  }
-  // Some env of the wave reset or ended (same-step mode): its prediction did not hold.
-  if (p.debug & 16) return;  // (timing probe)
-  unsigned long long todo = __ballot(lane < n_env && !same && (real.meta & 1u));
-  // envs whose prediction held: only the last vector
-  if (lane < n_env && same) {
-    float4_t v = load_global<float4_t>(real.src, (int64_t)(VPE - 1u));
-    float x[GTE_MAX_DYN];
-#pragma unroll
-    for (int i = 0; i < GTE_MAX_DYN; ++i) x[i] = L.cur[sl * GTE_MAX_DYN + i];
-    set_tail(v, p.nd, x);
-    store_out<NT>((float4_t*)(p.obs + (int64_t)real.env * V + (int64_t)(VPE - 1u) * 4), v);
-  }
-  // the others: the whole wave copies one env's window after the other from its REAL job, dynamic
-  // values of older rows straight from the env's ring in global memory (rare: ~N / duration envs per step)
-  while (todo) {  // wave-uniform
-    const int el = __ffsll((long long)todo) - 1;
-    todo &= todo - 1ull;
-    const int sr = s_first + el;
-    const JobRec j = L.job[sr];
-    const float* ring_e = p.ring + (int64_t)j.env * p.depth * p.nd;
-    const int nz = meta_n_zero(j.meta), slot0 = meta_slot0(j.meta);
-    for (uint32_t q = (uint32_t)lane; q < VPE; q += 64u) {
-      float4_t v = load_global<float4_t>(j.src, (int64_t)q);
-      const uint32_t w = fastdiv40(q, fv_magic);
-      if (q - w * FV == FV - 1u) {  // the row's last vector: its dynamic columns
-        int32_t slot = slot0 + (int32_t)w;
-        if (slot >= (int32_t)W) slot -= (int32_t)W;
-        float x[GTE_MAX_DYN];
-#pragma unroll
-        for (int i = 0; i < GTE_MAX_DYN; ++i) {
-          x[i] = 0.0f;
-          if (i < p.nd) {
-            if (w == W - 1u) x[i] = L.cur[sr * GTE_MAX_DYN + i];
-            else if ((int)w >= nz) x[i] = ring_e[(int64_t)slot * p.nd + i];
-          }
-        }
-        set_tail(v, p.nd, x);
-      }
-      store_out<NT>((float4_t*)(p.obs + (int64_t)j.env * V + (int64_t)q * 4), v);
-    }
-  }
 }
 
 #ifndef GTE_HOT_ONLY
@@ -1401,17 +1141,6 @@ hipError_t launch_rewind_queue(EnvRec* rec, int n, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// a dataset was replaced under running envs: the prices cached in their records are stale
-__global__ void gte_forget_prices_kernel(EnvRec* rec, int n) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n) rec[e].px_key = 0;
-}
-
-hipError_t launch_forget_prices(EnvRec* rec, int n, hipStream_t stream) {
-  hipLaunchKernelGGL(gte_forget_prices_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, rec, n);
-  return hipGetLastError();
-}
-
 // ---------------------------------------------------------------------------
 // launchers (called from gte_api.hip)
 
@@ -1419,8 +1148,7 @@ static uint64_t magic40(uint32_t d) { return ((1ull << 40) + d - 1) / d; }
 
 size_t lds_bytes(const Params& p, int stage) {
   const size_t EPB = (size_t)p.epw * GTE_WAVES;
-  size_t b = EPB * (16 + 4 * GTE_MAX_DYN + 4) + 8 * GTE_MAX_POSITIONS +
-             (p.final_obs ? EPB * sizeof(FinalJob) : 0);
+  size_t b = EPB * (16 + 64 + 4 * GTE_MAX_DYN + 4) + (p.final_obs ? EPB * sizeof(FinalJob) : 0);
   if (stage) b += EPB * (size_t)p.W * (size_t)(p.nd ? p.nd : 1) * 4;
   return b;
 }

@@ -252,11 +252,11 @@ __device__ __forceinline__ void resident_group(const Params& p0, const RolloutAr
   const bool active = owns && lane < n_wg;
   const int e0 = active ? (p0.perm ? p0.perm[wg_first + lane] : wg_first + lane) : 0;
   EnvRegs s = {};
-  PriceCarry pc = {0.0, 0.0, -1, 0};
-  if (active) load_state(p0, e0, s, &pc);  // (incl. the prices the record knows one step ahead)
+  if (active) load_state(p0, e0, s);
   int32_t act = active ? r.actions[e0] : -1;  // the next step's action, loaded one step ahead
   uint64_t prev_src = 0;
   int32_t prev_nz = -1;
+  PriceCarry pc = {0.0, 0.0, -1, 0};
   ObsJob job;
 
   auto run_a = [&](int k) {  // phase A of step k (wave 0), from and into the registers
@@ -264,7 +264,7 @@ __device__ __forceinline__ void resident_group(const Params& p0, const RolloutAr
     const int32_t a = act;
     if (active && k + 1 < r.K) act = r.actions[(int64_t)(k + 1) * p0.N + e0];
     double pv = 0.0;
-    phase_a<MODE_STEP, true>(p, e0, active, lane, job, nullptr, /*compact=*/k == r.K - 1, &pv, &s, &a,
+    phase_a<MODE_STEP>(p, e0, active, lane, job, nullptr, /*compact=*/k == r.K - 1, &pv, &s, &a,
                        /*write_record=*/k == r.K - 1, &pc);
     if (r.valuation && active) r.valuation[(int64_t)k * p0.N + e0] = pv;
     // An env that re-anchors (reset, dataset switch) will have its window refilled from the
@@ -477,9 +477,9 @@ __global__ __launch_bounds__(256) void gte_rollout_state_kernel(const Params p0,
   const bool active = lane < epw && slot < p0.N;
   const int e = active ? (p0.perm ? p0.perm[slot] : slot) : 0;
   EnvRegs s = {};
-  PriceCarry pc = {0.0, 0.0, -1, 0};
-  if (active) load_state(p0, e, s, &pc);
+  if (active) load_state(p0, e, s);
   int32_t act = active ? r.actions[e] : -1;
+  PriceCarry pc = {0.0, 0.0, -1, 0};
   ObsJob job;
   auto run_a = [&](int k) {
     const Params p = step_params(p0, r, k);
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void gte_rollout_state_kernel(const Params p0,
     double pv = 0.0;
     // the record is stored once, after the last step: its 128 B per env-step of scattered 16-byte
     // stores were most of what this kernel issued
-    phase_a<MODE_STEP, true>(p, e, active, lane, job, nullptr, /*compact=*/false, &pv, &s, &a,
+    phase_a<MODE_STEP>(p, e, active, lane, job, nullptr, /*compact=*/false, &pv, &s, &a,
                        /*write_record=*/k == n_steps - 1, &pc);
     if (r.valuation && active) r.valuation[(int64_t)k * p0.N + e] = pv;
   };
