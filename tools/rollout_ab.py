@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--share", action="store_true", help="--reuse with ONE set of output tensors for all variants")
     ap.add_argument("--prealloc", action="store_true",
                     help="--share with the output tensors allocated BEFORE anything else in the process")
+    ap.add_argument("--no-obs", action="store_true", help="state-only rollouts (keep_obs=False)")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     import torch
@@ -59,7 +60,7 @@ def main():
         for name, e in envs.items():
             e.timer_start()
             key = "shared" if a.share else name
-            o = e.rollout(acts, keep_obs=True, out=outs.get(key) if (a.reuse or a.share) else None)
+            o = e.rollout(acts, keep_obs=not a.no_obs, out=outs.get(key) if (a.reuse or a.share) else None)
             outs[key] = o
             print(f"rep {rep} {name:10s} {e.timer_stop() * 1e3 / a.k:7.2f} us/step", flush=True)
     for e in envs.values():
