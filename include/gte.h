@@ -129,7 +129,10 @@ typedef struct gte_config {
                                always inside the step kernel (default: whichever
                                measured faster for the batch size), 4096 = always the
                                generic copy loop (not the lean one that full waves of
-                               16-byte-vector windows take)                         */
+                               16-byte-vector windows take), 8192 = the lane that
+                               stepped an env stores its record itself (default: the
+                               record's per-step half goes through LDS and is
+                               written by the copy waves, one 64-byte request per env) */
   int32_t debug_flags;      /* timing ablations only (results become wrong):
                                1 = skip the observation gather, 2 = skip the
                                dynamic-column patch, 8 = skip the window loads

@@ -298,10 +298,11 @@ def test_hip_vs_oracle_shape_sweep(oracle_mod, shape, autoreset):
 
 
 @pytest.mark.parametrize("variant,store", [(0, 1), (0, 2), (0, 0), (1, 2), (2, 2), (3, 1), (64, 2),
-                                           (64, 1)])
+                                           (64, 1), (8192, 2), (8192 + 1, 2), (4096, 2)])
 def test_hip_vs_oracle_kernel_variants(oracle_mod, variant, store):
     """Every selectable kernel structure (isolated / shared-TU hot kernel, per-wave phase A, no
-    LDS staging) and store policy (plain / nt / sc1) gives the same results."""
+    LDS staging, record stored by the stepping lane instead of through LDS, generic copy loop) and
+    store policy (plain / nt / sc1) gives the same results."""
     ds = [_synthetic(71, 3000, 30, sigma=1e-2)]
     _compare_with_oracle(oracle_mod, ds, n_envs=6000, steps=60, seed=41, check_every=6,
                          windows=20, positions=[-1, 0, 1], trading_fees=1e-4,
