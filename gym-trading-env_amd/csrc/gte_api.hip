@@ -469,8 +469,8 @@ int gte_create(const gte_config* cfg, gte_env** out) {
     // Default re-sort period: the order decays as envs jump to new start rows, i.e. with the
     // reset rate, about 1 / max_episode_duration of the envs per step once the episodes are out
     // of phase.  Measured at duration 500, episodes staggered (profiles/r02_tune_affinity_period.log):
-    // every 128 steps 42.4 us per step, 64: 41.3, 32: 40.6, 16: 40.5, 8: 41.6 (a re-sort is four
-    // small launches, ~25 us) -> re-sort after ~6 % of the envs have moved; 128 when episodes
+    // every 128 steps 42.4 us per step, 64: 41.3, 32: 40.6, 16: 40.5, 8: 41.6 (a re-sort was four
+    // small launches then, ~25 us) -> re-sort after ~6 % of the envs have moved; 128 when episodes
     // only end by the drawdown rule or at the end of the data.
     int auto_period = 128;
     if (p.max_dur > 0) {
@@ -497,7 +497,7 @@ int gte_create(const gte_config* cfg, gte_env** out) {
       int rc2 = GTE_OK;
       if (rc2 == GTE_OK) rc2 = dev_alloc(E, &E->d_perm, N, false);
       if (rc2 == GTE_OK) rc2 = dev_alloc(E, &E->d_slot_of_rank, N, false);
-      if (rc2 == GTE_OK) rc2 = dev_alloc(E, &E->d_bins, (size_t)p.D * nb);
+      if (rc2 == GTE_OK) rc2 = dev_alloc(E, &E->d_bins, (size_t)2 * p.D * nb);  // histogram (zero-filled) + cursors
       if (rc2 == GTE_OK && hipMemcpy(E->d_slot_of_rank, slot_of_rank.data(), sizeof(int32_t) * N,
                                      hipMemcpyHostToDevice) != hipSuccess)
         rc2 = fail(GTE_ERR_HIP, "copying slot_of_rank failed");
@@ -749,7 +749,7 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
   }
   if (E->affinity_period > 0 && ++E->steps_since_rebuild >= E->affinity_period) {
     // envs drift one row per step and ~1/duration of them jump at a reset: re-sort now and
-    // then (4 tiny launches, stream-ordered between two steps)
+    // then (3 tiny launches, stream-ordered between two steps)
     HIPCHK(gte::launch_affinity_rebuild(E->p, E->d_bins, E->n_bins_per_ds, E->d_slot_of_rank,
                                         E->d_perm, E->stream));
     E->steps_since_rebuild = 0;

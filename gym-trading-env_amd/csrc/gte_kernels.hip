@@ -1058,8 +1058,10 @@ __global__ void gte_affinity_hist_kernel(const Params p, int32_t* hist, int n_bi
   atomicAdd(&hist[d * n_bins_per_ds + b], 1);
 }
 
-// exclusive scan of `hist` (n_bins <= 1024 * per_thread) by one workgroup
-__global__ __launch_bounds__(1024) void gte_affinity_scan_kernel(int32_t* hist, int n_bins) {
+// exclusive scan of `hist` (n_bins <= 1024 * per_thread) by one workgroup, into `cursor`; the
+// histogram is left ZEROED for the next re-sort (no memset launch per re-sort: the array is
+// zero-filled when it is allocated, and this kernel is its only reader)
+__global__ __launch_bounds__(1024) void gte_affinity_scan_kernel(int32_t* hist, int32_t* cursor, int n_bins) {
   __shared__ int32_t part[1024];
   const int t = threadIdx.x;
   const int per = (n_bins + 1023) / 1024;
@@ -1077,7 +1079,8 @@ __global__ __launch_bounds__(1024) void gte_affinity_scan_kernel(int32_t* hist, 
   int32_t run = part[t] - sum;  // exclusive prefix of this thread's chunk
   for (int i = lo; i < hi; ++i) {
     const int32_t c = hist[i];
-    hist[i] = run;
+    hist[i] = 0;
+    cursor[i] = run;
     run += c;
   }
 }
@@ -1097,14 +1100,13 @@ __global__ void gte_affinity_scatter_kernel(const Params p, int32_t* cursor, int
 hipError_t launch_affinity_rebuild(const Params& p, int32_t* bins, int n_bins_per_ds,
                                    const int32_t* slot_of_rank, int32_t* perm_out,
                                    hipStream_t stream) {
+  // bins: [0, n_bins) the histogram (zero between re-sorts), [n_bins, 2 n_bins) the scatter's cursors
   const int n_bins = p.D * n_bins_per_ds;
-  hipError_t e = hipMemsetAsync(bins, 0, sizeof(int32_t) * n_bins, stream);
-  if (e != hipSuccess) return e;
   const int blocks = (p.N + 255) / 256;
   hipLaunchKernelGGL(gte_affinity_hist_kernel, dim3(blocks), dim3(256), 0, stream, p, bins,
                      n_bins_per_ds);
-  hipLaunchKernelGGL(gte_affinity_scan_kernel, dim3(1), dim3(1024), 0, stream, bins, n_bins);
-  hipLaunchKernelGGL(gte_affinity_scatter_kernel, dim3(blocks), dim3(256), 0, stream, p, bins,
+  hipLaunchKernelGGL(gte_affinity_scan_kernel, dim3(1), dim3(1024), 0, stream, bins, bins + n_bins, n_bins);
+  hipLaunchKernelGGL(gte_affinity_scatter_kernel, dim3(blocks), dim3(256), 0, stream, p, bins + n_bins,
                      n_bins_per_ds, slot_of_rank, perm_out);
   return hipGetLastError();
 }
