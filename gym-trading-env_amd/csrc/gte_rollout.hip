@@ -546,6 +546,11 @@ int resident_blocks_per_cu(const Params& p, int epb, int nt) {
 hipError_t launch_rollout_resident(const Params& p, const RolloutArgs& r, int nt, int blocks,
                                    hipStream_t stream) {
   if (!hot_tu_covers(p)) return hipErrorInvalidValue;  // this TU is compiled with GTE_HOT_ONLY (gte_device.h)
+  // identity processing order: the windows live in LDS for the whole launch, so the L2-affinity
+  // order has one table row per env-step left to serve, while it scatters every step's return
+  // values (28.4 -> 28.0 us per step, profiles/r03_rollout_placement.log)
+  Params q = p;
+  q.perm = nullptr;
   const size_t smem = resident_lds_bytes(p, r.epb);
   auto magic = [](uint32_t d) { return ((1ull << 40) + d - 1) / d; };
   const uint32_t FV = (uint32_t)p.Fobs / 4u;
@@ -558,11 +563,11 @@ hipError_t launch_rollout_resident(const Params& p, const RolloutArgs& r, int nt
     if (e != hipSuccess) return e;
   }
   if (nt == 2)
-    hipLaunchKernelGGL((gte_rollout_resident_kernel<2>), dim3(blocks), dim3(256), smem, stream, p, r, vlm, fm);
+    hipLaunchKernelGGL((gte_rollout_resident_kernel<2>), dim3(blocks), dim3(256), smem, stream, q, r, vlm, fm);
   else if (nt == 1)
-    hipLaunchKernelGGL((gte_rollout_resident_kernel<1>), dim3(blocks), dim3(256), smem, stream, p, r, vlm, fm);
+    hipLaunchKernelGGL((gte_rollout_resident_kernel<1>), dim3(blocks), dim3(256), smem, stream, q, r, vlm, fm);
   else
-    hipLaunchKernelGGL((gte_rollout_resident_kernel<0>), dim3(blocks), dim3(256), smem, stream, p, r, vlm, fm);
+    hipLaunchKernelGGL((gte_rollout_resident_kernel<0>), dim3(blocks), dim3(256), smem, stream, q, r, vlm, fm);
   return hipGetLastError();
 }
 
