@@ -151,7 +151,7 @@ class GteLogView(C.Structure):
                 ("real_position", C.c_void_p), ("reward", C.c_void_p), ("flags", C.c_void_p),
                 ("rows", C.c_int64), ("L", C.c_int32), ("N", C.c_int32),
                 ("asset", C.c_void_p), ("fiat", C.c_void_p), ("interest_asset", C.c_void_p),
-                ("interest_fiat", C.c_void_p)]
+                ("interest_fiat", C.c_void_p), ("env_stride", C.c_int64), ("row_stride", C.c_int64)]
 
 
 class GteLogBatch(C.Structure):

@@ -562,9 +562,11 @@ class BatchedTradingEnv(_VectorEnvBase):
         if t is None:
             v, dt = self._log_view(), np.dtype(_abi.LOG_DTYPES[name])
 
+            # the log is one array of records [L, N]: a column is a strided view of it
             class _Raw:
                 __cuda_array_interface__ = {
-                    "shape": (int(v.L), int(v.N)), "typestr": dt.str, "version": 2, "strides": None,
+                    "shape": (int(v.L), int(v.N)), "typestr": dt.str, "version": 2,
+                    "strides": (int(v.row_stride), int(v.env_stride)),
                     "data": (int(getattr(v, name)), False)}
             t = self._torch.as_tensor(_Raw(), device=self._t["obs"].device)
             self._log_tensors[name] = t
@@ -582,10 +584,15 @@ class BatchedTradingEnv(_VectorEnvBase):
                 return t[int(phys)]
             return t[phys.long(), self._torch.arange(N, device=t.device)]
         v, dt = self._log_view(), np.dtype(_abi.LOG_DTYPES[name])
-        base = int(getattr(v, name))
+        base, es, rs = int(getattr(v, name)), int(v.env_stride), int(v.row_stride)
+
+        def rows_to_host(first, count):  # the records of `count` rows in one copy; the column = a strided view
+            nbytes = (count - 1) * rs + (N - 1) * es + dt.itemsize
+            raw = self._to_host(base + first * rs, np.dtype(np.uint8), nbytes)
+            return np.ndarray(shape=(count, N), dtype=dt, buffer=raw, strides=(rs, es)).copy()
         if phys is not None and np.ndim(phys) == 0:
-            return self._to_host(base + int(phys) * N * dt.itemsize, dt, N)
-        whole = self._to_host(base, dt, int(v.L) * N).reshape(int(v.L), N)
+            return rows_to_host(int(phys), 1)[0]
+        whole = rows_to_host(0, int(v.L))
         return whole[order] if phys is None else whole[np.asarray(phys), np.arange(N)]
 
     def _log_row(self, name, phys, raw=False):

@@ -41,8 +41,8 @@ hipError_t launch_rollout_state(const Params& p, const RolloutArgs& r, int n_ste
                                 hipStream_t stream);
 hipError_t launch_set_dynamic_columns(const Params& p, const void* const* cols, const int32_t* is_f64,
                                       hipStream_t stream);
-hipError_t launch_apply_reward(const Params& p, const double* reward, const int32_t* log_step_row,
-                               double* log_reward_row, int terminal_view, hipStream_t stream);
+hipError_t launch_apply_reward(const Params& p, const double* reward, LogRow* newest, int terminal_view,
+                               hipStream_t stream);
 hipError_t launch_rollout(const Params& p, const RolloutArgs& r, int nt, int blocks, int threads,
                           hipStream_t stream);
 int rollout_blocks_per_cu(const Params& p, int nt);
@@ -336,12 +336,7 @@ int gte_create(const gte_config* cfg, gte_env** out) {
   chk(dev_alloc(E, &E->d_inj_ds, N));
   if (cfg->log_steps > 0) {
     const size_t LN = (size_t)cfg->log_steps * N;
-    chk(dev_alloc(E, &E->log.idx, LN)); chk(dev_alloc(E, &E->log.step, LN));
-    chk(dev_alloc(E, &E->log.pos, LN)); chk(dev_alloc(E, &E->log.dsi, LN));
-    chk(dev_alloc(E, &E->log.pv, LN)); chk(dev_alloc(E, &E->log.realpos, LN));
-    chk(dev_alloc(E, &E->log.reward, LN)); chk(dev_alloc(E, &E->log.flags, LN));
-    chk(dev_alloc(E, &E->log.asset, LN)); chk(dev_alloc(E, &E->log.fiat, LN));
-    chk(dev_alloc(E, &E->log.ia, LN)); chk(dev_alloc(E, &E->log.ifi, LN));
+    chk(dev_alloc(E, &E->log.rows, LN));  // 80 B per (row, env)
   }
   double* d_pos = nullptr;
   chk(dev_alloc(E, &d_pos, GTE_MAX_POSITIONS));
@@ -766,14 +761,14 @@ int gte_step(gte_env* E, const int32_t* actions, int32_t actions_on_device) {
   E->term_slot ^= 1;
   p.term_count = E->term_base + E->term_slot;
   p.term_count_next = E->term_base + (E->term_slot ^ 1);
-  // With a trajectory log the step kernel writes the row itself (shared-TU instantiation, same
-  // speed as the isolated ones at today's geometry, profiles/r02_mode_bench.log) where that beats
-  // a second launch (profiles/r02_log_ab.log, config-3 shape, us per step kernel row / separate):
-  // 8 192 envs 11.2 / 14.3, 16 384: 16.0 / 19.0, 32 768: 27.6 / 26.8, 65 536: 49.1 / 44.7 with the
-  // L2-affinity order (the row's 12 stores per lane are scattered then); 53.5 / 57.4 without it.
-  // kernel_variant bit 1024 always keeps the separate gte_log_kernel launch, 2048 never does.
-  const bool fused_log = E->cfg.log_steps > 0 && !(E->cfg.kernel_variant & 1024) &&
-                         ((E->cfg.kernel_variant & 2048) || !p.perm || p.N <= 16384);
+  // With a trajectory log the step kernel writes the row itself (shared-TU instantiation): the lane
+  // that stepped the env puts its 80-byte record into LDS and the copy waves write it out, five
+  // lanes per env.  At the config-3 shape, us per step: 38.5 against 43.2 with the separate
+  // gte_log_kernel launch (and 37.5 without a log; profiles/r03_log_ab.log).  (Rounds 1-2 kept the
+  // log as twelve [L, N] columns: twelve scattered stores per env from the stepping lane, which
+  // beyond 16 384 envs lost to the separate launch.)
+  // kernel_variant bit 1024 keeps the separate launch (A/B), 2048 = the default now.
+  const bool fused_log = E->cfg.log_steps > 0 && !(E->cfg.kernel_variant & 1024);
   if (fused_log) {
     p.log = E->log;
     p.log_row_base = (E->log_rows % E->cfg.log_steps) * (int64_t)p.N;
@@ -1013,26 +1008,31 @@ int gte_add_limit_orders(gte_env* E, const int32_t* pos_index, const double* lim
 int gte_get_log(gte_env* E, gte_log_view* out) {
   if (!E || !out) return fail(GTE_ERR_INVALID, "NULL argument");
   if (E->cfg.log_steps <= 0) return fail(GTE_ERR_STATE, "created with log_steps = 0");
-  out->idx = E->log.idx; out->step = E->log.step; out->position_index = E->log.pos;
-  out->dataset_index = E->log.dsi; out->portfolio_valuation = E->log.pv;
-  out->real_position = E->log.realpos; out->reward = E->log.reward; out->flags = E->log.flags;
+  gte::LogRow* r = E->log.rows;  // the columns as strided views of the [L, N] rows
+  out->idx = &r->idx; out->step = &r->step; out->position_index = &r->pos;
+  out->dataset_index = &r->dsi; out->portfolio_valuation = &r->pv;
+  out->real_position = &r->realpos; out->reward = &r->reward; out->flags = &r->flags;
   out->rows = E->log_rows; out->L = E->cfg.log_steps; out->N = E->p.N;
-  out->asset = E->log.asset; out->fiat = E->log.fiat;
-  out->interest_asset = E->log.ia; out->interest_fiat = E->log.ifi;
+  out->asset = &r->asset; out->fiat = &r->fiat;
+  out->interest_asset = &r->ia; out->interest_fiat = &r->ifi;
+  out->env_stride = (int64_t)sizeof(gte::LogRow);
+  out->row_stride = (int64_t)sizeof(gte::LogRow) * E->p.N;
   return GTE_OK;
 }
 
 // rows first .. first+n-1 (mod L) of ONE env, oldest first: at most two strided 2-D copies per array
 static int pull_log_column(gte_env* E, int32_t env_id, int64_t first, int32_t n, void* host,
-                           const void* dev, size_t elem) {
+                           size_t offset, size_t elem) {
   if (!host) return GTE_OK;
   const int N = E->p.N, L = E->cfg.log_steps;
+  const size_t pitch = sizeof(gte::LogRow) * (size_t)N;  // the same env, one row later
+  const char* col = (const char*)E->log.rows + offset + sizeof(gte::LogRow) * (size_t)env_id;
   const int64_t run1 = (first + n <= L) ? n : (L - first);
-  HIPCHK(hipMemcpy2D(host, elem, (const char*)dev + ((size_t)first * N + env_id) * elem,
-                     (size_t)N * elem, elem, (size_t)run1, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy2D(host, elem, col + (size_t)first * pitch, pitch, elem, (size_t)run1,
+                     hipMemcpyDeviceToHost));
   if (run1 < n)
-    HIPCHK(hipMemcpy2D((char*)host + run1 * elem, elem, (const char*)dev + (size_t)env_id * elem,
-                       (size_t)N * elem, elem, (size_t)(n - run1), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy2D((char*)host + run1 * elem, elem, col, pitch, elem, (size_t)(n - run1),
+                       hipMemcpyDeviceToHost));
   return GTE_OK;
 }
 
@@ -1059,14 +1059,14 @@ int gte_read_log(gte_env* E, int32_t env_id, int32_t n, int32_t* idx, int32_t* s
   int64_t first = 0;
   TRY(log_window(E, env_id, &n, n_out, &first));
   if (n == 0) return GTE_OK;
-  TRY(pull_log_column(E, env_id, first, n, idx, E->log.idx, 4));
-  TRY(pull_log_column(E, env_id, first, n, step, E->log.step, 4));
-  TRY(pull_log_column(E, env_id, first, n, position_index, E->log.pos, 4));
-  TRY(pull_log_column(E, env_id, first, n, dataset_index, E->log.dsi, 4));
-  TRY(pull_log_column(E, env_id, first, n, portfolio_valuation, E->log.pv, 8));
-  TRY(pull_log_column(E, env_id, first, n, real_position, E->log.realpos, 8));
-  TRY(pull_log_column(E, env_id, first, n, reward, E->log.reward, 8));
-  TRY(pull_log_column(E, env_id, first, n, flags, E->log.flags, 1));
+  TRY(pull_log_column(E, env_id, first, n, idx, offsetof(gte::LogRow, idx), 4));
+  TRY(pull_log_column(E, env_id, first, n, step, offsetof(gte::LogRow, step), 4));
+  TRY(pull_log_column(E, env_id, first, n, position_index, offsetof(gte::LogRow, pos), 4));
+  TRY(pull_log_column(E, env_id, first, n, dataset_index, offsetof(gte::LogRow, dsi), 4));
+  TRY(pull_log_column(E, env_id, first, n, portfolio_valuation, offsetof(gte::LogRow, pv), 8));
+  TRY(pull_log_column(E, env_id, first, n, real_position, offsetof(gte::LogRow, realpos), 8));
+  TRY(pull_log_column(E, env_id, first, n, reward, offsetof(gte::LogRow, reward), 8));
+  TRY(pull_log_column(E, env_id, first, n, flags, offsetof(gte::LogRow, flags), 1));
   return GTE_OK;
 }
 
@@ -1075,10 +1075,10 @@ int gte_read_log_portfolio(gte_env* E, int32_t env_id, int32_t n, double* asset,
   int64_t first = 0;
   TRY(log_window(E, env_id, &n, n_out, &first));
   if (n == 0) return GTE_OK;
-  TRY(pull_log_column(E, env_id, first, n, asset, E->log.asset, 8));
-  TRY(pull_log_column(E, env_id, first, n, fiat, E->log.fiat, 8));
-  TRY(pull_log_column(E, env_id, first, n, interest_asset, E->log.ia, 8));
-  TRY(pull_log_column(E, env_id, first, n, interest_fiat, E->log.ifi, 8));
+  TRY(pull_log_column(E, env_id, first, n, asset, offsetof(gte::LogRow, asset), 8));
+  TRY(pull_log_column(E, env_id, first, n, fiat, offsetof(gte::LogRow, fiat), 8));
+  TRY(pull_log_column(E, env_id, first, n, interest_asset, offsetof(gte::LogRow, ia), 8));
+  TRY(pull_log_column(E, env_id, first, n, interest_fiat, offsetof(gte::LogRow, ifi), 8));
   return GTE_OK;
 }
 
@@ -1134,8 +1134,8 @@ int gte_set_log_reward(gte_env* E, const double* reward_device) {
   if (E->cfg.log_steps <= 0) return fail(GTE_ERR_STATE, "created with log_steps = 0");
   if (E->log_rows <= 0) return fail(GTE_ERR_STATE, "the log is empty");
   const int64_t row = (E->log_rows - 1) % E->cfg.log_steps;
-  HIPCHK(hipMemcpyAsync(E->log.reward + row * (int64_t)E->p.N, reward_device, sizeof(double) * (size_t)E->p.N,
-                        hipMemcpyDeviceToDevice, E->stream));
+  HIPCHK(hipMemcpy2DAsync(&E->log.rows[row * (int64_t)E->p.N].reward, sizeof(gte::LogRow), reward_device,
+                          sizeof(double), sizeof(double), (size_t)E->p.N, hipMemcpyDeviceToDevice, E->stream));
   return GTE_OK;
 }
 
@@ -1145,8 +1145,8 @@ int gte_apply_reward(gte_env* E, const double* reward_device, int32_t terminal_v
   if (E->log_rows <= 0) return fail(GTE_ERR_STATE, "the log is empty");
   HIPCHK(hipSetDevice(E->cfg.device));
   const int64_t row = (E->log_rows - 1) % E->cfg.log_steps;
-  HIPCHK(gte::launch_apply_reward(E->p, reward_device, E->log.step + row * (int64_t)E->p.N,
-                                  E->log.reward + row * (int64_t)E->p.N, terminal_view ? 1 : 0, E->stream));
+  HIPCHK(gte::launch_apply_reward(E->p, reward_device, E->log.rows + row * (int64_t)E->p.N,
+                                  terminal_view ? 1 : 0, E->stream));
   return GTE_OK;
 }
 

@@ -13,14 +13,17 @@ __global__ void gte_log_kernel(const EnvRec* rec, const double* reward64, const 
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   const EnvRec r = rec[e];
-  const int64_t k = row_base + e;
-  o.idx[k] = r.idx; o.step[k] = r.step; o.pos[k] = r.pos; o.dsi[k] = r.dsi;
+  LogRow w;
+  w.idx = r.idx; w.step = r.step; w.pos = r.pos; w.dsi = r.dsi;
   // a row a reset wrote carries reward 0 (environments.py:196) — also when the reset ran inside
   // the step that ended the episode (same-step mode: the terminal step's reward is in the return
   // buffers and in final_info, this row already describes the new episode)
-  o.pv[k] = r.pv; o.realpos[k] = r.realpos; o.reward[k] = (r.step == 0) ? 0.0 : reward64[e];
-  o.asset[k] = r.asset; o.fiat[k] = r.fiat; o.ia[k] = r.ia; o.ifi[k] = r.ifi;
-  o.flags[k] = (uint8_t)((term[e] ? 1 : 0) | (trunc[e] ? 2 : 0));
+  w.pv = r.pv; w.realpos = r.realpos; w.reward = (r.step == 0) ? 0.0 : reward64[e];
+  w.asset = r.asset; w.fiat = r.fiat; w.ia = r.ia; w.ifi = r.ifi;
+  w.flags = (uint8_t)((term[e] ? 1 : 0) | (trunc[e] ? 2 : 0));
+#pragma unroll
+  for (int i = 0; i < 7; ++i) w.pad[i] = 0;
+  o.rows[row_base + e] = w;
 }
 
 hipError_t launch_log(const EnvRec* rec, const double* reward64, const uint8_t* term,
@@ -99,24 +102,25 @@ hipError_t launch_set_dynamic_columns(const Params& p, const void* const* cols, 
 // terminal_view (same-step auto-reset): an env that ended shows its TERMINAL row to the callable,
 // so the reset row underneath does not zero the reward it RETURNS; the log row itself — the reset
 // row of the next episode — keeps the reference's 0.
-__global__ void gte_apply_reward_kernel(const Params p, const double* reward, const int32_t* log_step_row,
-                                        double* log_reward_row, int terminal_view) {
+__global__ void gte_apply_reward_kernel(const Params p, const double* reward, LogRow* newest,
+                                        int terminal_view) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= p.N) return;
   const bool term = p.terminated[e] != 0;
   const bool ended = term || p.truncated[e] != 0;
-  bool reset_row = log_step_row[e] == 0;
+  const bool log_reset_row = newest[e].step == 0;
+  bool reset_row = log_reset_row;
   if (terminal_view) reset_row = reset_row && !ended;
   const double r = (term || reset_row) ? 0.0 : reward[e];
   p.reward64[e] = r;
   p.reward[e] = (float)r;
-  log_reward_row[e] = (log_step_row[e] == 0) ? 0.0 : r;  // the log row of a reset keeps reward 0 (:196)
+  newest[e].reward = log_reset_row ? 0.0 : r;  // the log row of a reset keeps reward 0 (:196)
 }
 
-hipError_t launch_apply_reward(const Params& p, const double* reward, const int32_t* log_step_row,
-                               double* log_reward_row, int terminal_view, hipStream_t stream) {
+hipError_t launch_apply_reward(const Params& p, const double* reward, LogRow* newest, int terminal_view,
+                               hipStream_t stream) {
   hipLaunchKernelGGL(gte_apply_reward_kernel, dim3((p.N + 255) / 256), dim3(256), 0, stream, p, reward,
-                     log_step_row, log_reward_row, terminal_view);
+                     newest, terminal_view);
   return hipGetLastError();
 }
 
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) void gte_pack_log_kernel(const LogArrays log, 
   const long long base = rows_written - have;
   auto at = [&](int r) -> int64_t { return (int64_t)((base + r) % L) * N + e; };
   const bool fin = finished != 0;
-  auto step_at = [&](int r) -> int32_t { return (fin && r == have - 1) ? final_rec[e].step : log.step[at(r)]; };
+  auto step_at = [&](int r) -> int32_t { return (fin && r == have - 1) ? final_rec[e].step : log.rows[at(r)].step; };
   const int32_t s_new = step_at(have - 1);
   int r0 = have - 1 - s_new;
   if (r0 < 0) r0 = 0;
@@ -173,11 +177,12 @@ __global__ __launch_bounds__(256) void gte_pack_log_kernel(const LogArrays log, 
       o.pv[d] = t.pv; o.realpos[d] = t.realpos; o.reward[d] = reward64[e];
       o.asset[d] = t.asset; o.fiat[d] = t.fiat; o.ia[d] = t.ia; o.ifi[d] = t.ifi;
     } else {
-      o.idx[d] = log.idx[k]; o.step[d] = log.step[k]; o.pos[d] = log.pos[k]; o.dsi[d] = log.dsi[k];
-      o.pv[d] = log.pv[k]; o.realpos[d] = log.realpos[k]; o.reward[d] = log.reward[k];
-      o.asset[d] = log.asset[k]; o.fiat[d] = log.fiat[k]; o.ia[d] = log.ia[k]; o.ifi[d] = log.ifi[k];
+      const LogRow w = log.rows[k];
+      o.idx[d] = w.idx; o.step[d] = w.step; o.pos[d] = w.pos; o.dsi[d] = w.dsi;
+      o.pv[d] = w.pv; o.realpos[d] = w.realpos; o.reward[d] = w.reward;
+      o.asset[d] = w.asset; o.fiat[d] = w.fiat; o.ia[d] = w.ia; o.ifi[d] = w.ifi;
     }
-    o.flags[d] = log.flags[k];
+    o.flags[d] = log.rows[k].flags;
   }
 }
 

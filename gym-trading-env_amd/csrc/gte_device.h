@@ -49,13 +49,22 @@ struct alignas(128) EnvRec {
 static_assert(offsetof(EnvRec, start) == 64, "EnvRec: the hot half is the first 64 bytes");
 static_assert(sizeof(EnvRec) == 128, "EnvRec must be one 128-byte line");
 
-// Trajectory log (optional, gte_config.log_steps): [L, N] arrays, one row per env after every
-// reset / step — what History.add records (reference environments.py:253-264).
+// Trajectory log (optional, gte_config.log_steps): [L, N] ROWS, one 80-byte record per env after
+// every reset / step — what History.add records (reference environments.py:253-264).  One record
+// per (row, env), not one array per column: the step kernel writes a row through LDS as two
+// requests per env, where the twelve columns were twelve scattered stores (one request each: what a
+// scattered store costs is per request, profiles/r03_phase_a_stores.log).  Hosts see the columns as
+// strided views (gte_log_view: env_stride / row_stride).
+struct alignas(16) LogRow {
+  int32_t idx, step, pos, dsi;                              // 16 B
+  double pv, realpos, reward;                               // 24 B
+  double asset, fiat, ia, ifi;  // Portfolio state: get_portfolio_distribution (portfolio.py:49-57)
+  uint8_t flags;                // bit0 terminated, bit1 truncated
+  uint8_t pad[7];                                           // -> 80 B
+};
+static_assert(sizeof(LogRow) == 80, "LogRow is five 16-byte pieces");
 struct LogArrays {
-  int32_t *idx, *step, *pos, *dsi;
-  double *pv, *realpos, *reward;
-  uint8_t* flags;
-  double *asset, *fiat, *ia, *ifi;  // Portfolio state: get_portfolio_distribution (portfolio.py:49-57)
+  LogRow* rows;  // [L, N]
 };
 
 // Everything a launch needs; passed by value as the kernel argument.
@@ -116,7 +125,7 @@ struct Params {
 // and every `#ifndef GTE_HOT_ONLY` block inside phase A names a field tested here.  Round 2
 // shipped a launch predicate that had drifted from the compiled-out store: final_info read
 // zero-filled records at every 16-byte-vector shape.
-inline bool hot_tu_covers(const Params& p) { return p.final_rec == nullptr && p.log.idx == nullptr; }
+inline bool hot_tu_covers(const Params& p) { return p.final_rec == nullptr && p.log.rows == nullptr; }
 
 // ---------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011).  One block of four draws per

@@ -545,16 +545,18 @@ struct WgLds {
   int32_t* idx;     // [EPB] current row (persist mode's zero-fill needs it)
   float* cur;       // [EPB][GTE_MAX_DYN] dynamic features of the current row
   FinalJob* fin;    // [EPB] terminal windows (only when p.final_obs)
+  unsigned char* logrow;  // [EPB][sizeof(LogRow)] the step's trajectory rows (only when p.log.rows; flush_log_rows)
   float* staged;    // [EPB][W][nd]: the raw rings; the lean copy loop resolves a wave's part IN
                     // PLACE into window order (rotation / zero rows / current row applied)
 };
 
-__device__ inline WgLds carve_lds(unsigned char* base, int EPB, bool with_final) {
+__device__ inline WgLds carve_lds(unsigned char* base, int EPB, bool with_final, bool with_log) {
   WgLds L;
   L.job = (JobRec*)base;                   base += 16 * EPB;
   L.hot = base;                            base += 64 * EPB;
   L.cur = (float*)base;                    base += 4 * GTE_MAX_DYN * EPB;
   L.idx = (int32_t*)base;                  base += 4 * EPB;
+  L.logrow = base;                         base += with_log ? sizeof(LogRow) * EPB : 0;  // (16-byte aligned here)
   L.fin = (FinalJob*)base;                 base += with_final ? sizeof(FinalJob) * EPB : 0;
   L.staged = (float*)base;
   return L;
@@ -570,6 +572,19 @@ __device__ inline void flush_hot_records(const Params& p, const WgLds& L, int s_
     const int env = L.job[sl].env;  // (>= 0 for the first n_env slots)
     const f4 v = *reinterpret_cast<const f4*>(L.hot + 64 * sl + 16 * part);
     *(reinterpret_cast<f4*>(&p.rec[env]) + part) = v;
+  }
+}
+
+// The step's trajectory rows, from the LDS image phase A's lanes left to the log: five lanes per env
+// (80 contiguous bytes, two requests per env where the twelve columns were twelve).
+__device__ inline void flush_log_rows(const Params& p, const WgLds& L, int s_first, int n_env, int lane) {
+  typedef float __attribute__((ext_vector_type(4))) f4;
+  for (int i = lane; i < n_env * 5; i += 64) {
+    const int q = i / 5, part = i - q * 5;
+    const int sl = s_first + q;
+    const int env = L.job[sl].env;  // (>= 0 for the first n_env slots)
+    const f4 v = *reinterpret_cast<const f4*>(L.logrow + sizeof(LogRow) * sl + 16 * part);
+    *(reinterpret_cast<f4*>(&p.log.rows[p.log_row_base + env]) + part) = v;
   }
 }
 
@@ -926,7 +941,7 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
   if (wg_first >= p.N) return;  // whole workgroup exits together (before any barrier)
   const int n_wg = min(EPB, p.N - wg_first);
   GTE_STAMP(0);
-  const WgLds L = carve_lds(gte_smem, EPB, p.final_obs != nullptr);
+  const WgLds L = carve_lds(gte_smem, EPB, p.final_obs != nullptr, p.log.rows != nullptr);
   const int s_first = wib * p.epw;
   const int n_env = min(p.epw, n_wg - s_first);
   // Which env each slot processes (identity, or the L2-affinity permutation), and the raw
@@ -967,19 +982,28 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
     // a step's record stores: into the LDS image (one 64-byte request per env after the barrier)
     const lds_byte_ptr hot = (MODE == MODE_STEP && p.hot_lds) ? (lds_byte_ptr)(L.hot + 64 * s) : (lds_byte_ptr) nullptr;
 #ifndef GTE_HOT_ONLY  // p.log: hot_tu_covers() keeps such launches off the isolated TUs
-    if (MODE == MODE_STEP && p.log.idx) {
-      // gte_step with log_steps: the lane that stepped the env also writes its trajectory row —
+    if (MODE == MODE_STEP && p.log.rows) {
+      // gte_step with log_steps: the lane that stepped the env also produces its trajectory row —
       // what History.add records (environments.py:253-264) — from its registers, instead of a
-      // second launch reading everything back (4.5 us per step)
+      // second launch reading everything back; the row goes to LDS and the copy waves write it
+      // out, five lanes per env (flush_log_rows)
       StepOut so = {};
       phase_a<MODE>(p, e, active, lane, job, p.final_obs ? &fin : nullptr, true, nullptr, nullptr, nullptr,
                     true, nullptr, &so, hot);
       if (active) {
-        const int64_t k = p.log_row_base + e;
-        p.log.idx[k] = so.idx; p.log.step[k] = so.step; p.log.pos[k] = so.pos; p.log.dsi[k] = so.dsi;
-        p.log.pv[k] = so.pv; p.log.realpos[k] = so.realpos; p.log.reward[k] = (so.step == 0) ? 0.0 : so.reward;  // reset rows: 0 (:196)
-        p.log.asset[k] = so.asset; p.log.fiat[k] = so.fiat; p.log.ia[k] = so.ia; p.log.ifi[k] = so.ifi;
-        p.log.flags[k] = (uint8_t)so.flags;
+        typedef int4_t __attribute__((address_space(3))) * li4;
+        typedef double2_t __attribute__((address_space(3))) * ld2;
+        const lds_byte_ptr w = (lds_byte_ptr)(L.logrow + sizeof(LogRow) * s);
+        int4_t a = {so.idx, so.step, so.pos, so.dsi};
+        double2_t d0 = {so.pv, so.realpos};
+        double2_t d1 = {(so.step == 0) ? 0.0 : so.reward, so.asset};  // reset rows: reward 0 (:196)
+        double2_t d2 = {so.fiat, so.ia};
+        double2_t d3 = {so.ifi, __longlong_as_double((long long)(so.flags & 0xff))};  // flags byte + zero padding
+        *(li4)w = a;
+        *(ld2)(w + 16) = d0;
+        *(ld2)(w + 32) = d1;
+        *(ld2)(w + 48) = d2;
+        *(ld2)(w + 64) = d3;
       }
     } else
 #endif
@@ -996,6 +1020,9 @@ __global__ __launch_bounds__(256) void gte_kernel(const Params p, const uint64_t
 
   // ---- phase B: each wave writes out the records of its own EPW envs and gathers their windows
   if (MODE == MODE_STEP && p.hot_lds && n_env > 0) flush_hot_records(p, L, s_first, n_env, lane);
+#ifndef GTE_HOT_ONLY  // p.log: hot_tu_covers() keeps such launches off the isolated TUs
+  if (MODE == MODE_STEP && p.log.rows && n_env > 0) flush_log_rows(p, L, s_first, n_env, lane);
+#endif
   if (n_env <= 0 || (p.debug & 1)) return;
   if (p.persist) zero_fresh_stores(p, L, s_first, n_env, lane);
   if (STAGE == STAGE_LATE) {
@@ -1150,7 +1177,8 @@ static uint64_t magic40(uint32_t d) { return ((1ull << 40) + d - 1) / d; }
 
 size_t lds_bytes(const Params& p, int stage) {
   const size_t EPB = (size_t)p.epw * GTE_WAVES;
-  size_t b = EPB * (16 + 64 + 4 * GTE_MAX_DYN + 4) + (p.final_obs ? EPB * sizeof(FinalJob) : 0);
+  size_t b = EPB * (16 + 64 + 4 * GTE_MAX_DYN + 4) + (p.final_obs ? EPB * sizeof(FinalJob) : 0) +
+             (p.log.rows ? EPB * sizeof(LogRow) : 0);
   if (stage) b += EPB * (size_t)p.W * (size_t)(p.nd ? p.nd : 1) * 4;
   return b;
 }

@@ -125,9 +125,9 @@ typedef struct gte_config {
                                where the fused kernels apply, 256 = gte_rollout uses
                                the gather-per-step fused kernel instead of the
                                window-resident one, 1024 = gte_step always appends
-                               the trajectory row with a separate small launch, 2048 =
-                               always inside the step kernel (default: whichever
-                               measured faster for the batch size), 4096 = always the
+                               the trajectory row with a separate small launch
+                               (default: the step kernel writes it, through LDS; 2048
+                               is accepted and means the default), 4096 = always the
                                generic copy loop (not the lean one that full waves of
                                16-byte-vector windows take), 8192 = the lane that
                                stepped an env stores its record itself (default: the
@@ -259,12 +259,15 @@ int gte_set_dynamic_features(gte_env* env, const float* values_device, uint32_t 
  * Both arrays are HOST arrays of n_dyn entries. */
 int gte_set_dynamic_columns(gte_env* env, const void* const* columns_device, const int32_t* is_f64);
 
-/* Device trajectory log (gte_config.log_steps = L): after every gte_reset / gte_step a small
- * kernel appends one row per env.  Row r of env e lives at index (r % L) * N + e of each
- * array; `rows` counts the rows written so far (the newest is rows - 1).  An episode of
+/* Device trajectory log (gte_config.log_steps = L): after every gte_reset / gte_step one row per
+ * env is appended (by the step kernel itself, or by a small launch).  The log is ONE array of
+ * 80-byte records [L, N] (the step kernel writes a row as two requests per env); the pointers
+ * below address column c of row 0, env 0, and element (r, e) of a column lives `row_stride`
+ * bytes per row and `env_stride` bytes per env further: p + (r % L) * row_stride + e *
+ * env_stride.  `rows` counts the rows written so far (the newest is rows - 1).  An episode of
  * env e is the run of rows whose `step` goes 0, 1, 2, ... (step 0 = the reset row). */
 typedef struct gte_log_view {
-  int32_t* idx;             /* i32 [L, N] _idx                                    */
+  int32_t* idx;             /* i32 [L, N] _idx  (strided, see above)               */
   int32_t* step;            /* i32 [L, N] _step                                   */
   int32_t* position_index;  /* i32 [L, N]                                         */
   int32_t* dataset_index;   /* i32 [L, N]                                         */
@@ -279,6 +282,8 @@ typedef struct gte_log_view {
   double*  fiat;            /*   interest_fiat: what `portfolio_distribution_*`      */
   double*  interest_asset;  /*   derives from (portfolio.py:49-57, History columns   */
   double*  interest_fiat;   /*   environments.py:262)                                */
+  int64_t  env_stride;      /* bytes from env e to env e + 1 of the same row          */
+  int64_t  row_stride;      /* bytes from row r to row r + 1 of the same env          */
 } gte_log_view;
 int gte_get_log(gte_env* env, gte_log_view* out);
 /* the last `n` (<= L) rows of ONE env, oldest first, into host arrays of length n (any may

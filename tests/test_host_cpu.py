@@ -238,8 +238,8 @@ def test_features_compiled_out_of_the_hot_translation_units_are_guarded():
     fields = [re.match(r"\s*//\s*p\.([a-z_]+)", b) for b in blocks]
     named = [m.group(1) for m in fields if m]
     assert len(blocks) - len(named) == 2, "an #ifndef GTE_HOT_ONLY block inside phase A does not name its field"
-    assert sorted(named) == ["final_rec", "log"]
-    for f in named:
+    assert sorted(set(named)) == ["final_rec", "log"]
+    for f in set(named):
         assert re.search(rf"p\.{f}\b", body), f"hot_tu_covers does not test p.{f}"
     api = read("gte_api.hip")
     assert re.search(r"const bool hot = [^;]*gte::hot_tu_covers\(p\)", api)
