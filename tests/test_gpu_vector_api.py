@@ -828,3 +828,42 @@ def test_verbose_prints_the_reference_episode_end_lines(capsys):
     batch.close(); big.close(); quiet.close()
     for s in singles:
         s.close()
+
+
+@pytest.mark.parametrize("n_envs", [96, 20_000])
+def test_log_columns_as_strided_views_of_the_records(n_envs):
+    """The trajectory log is one array of records [L, N] (`gte_log_view.row_stride / env_stride`);
+    its columns reach Python as strided device views (torch) or strided host copies (numpy): both
+    equal what `gte_read_log` returns per env, for rows the step kernel wrote itself (big batch
+    with the L2-affinity order included) and through the ring wrap of the log."""
+    import torch
+    import gym_trading_env_amd as gte
+    from gym_trading_env_amd import _abi
+    feat, close = _walk(77, 4000, 6, sigma=1e-2)
+    df = make_df(feat, close)
+    L = 5
+    kw = dict(positions=[-1, 0, 1], windows=4, trading_fees=1e-3, max_episode_duration=7, seed=4, log_steps=L)
+    et = gte.BatchedTradingEnv(df, n_envs, output="torch", **kw)
+    en = gte.BatchedTradingEnv(df, n_envs, output="numpy", **kw)
+    et.reset(); en.reset()
+    rng = np.random.default_rng(1)
+    for k in range(8):  # 9 rows written: the 5-row log has wrapped
+        a = rng.integers(0, 3, n_envs).astype(np.int32)
+        et.step(torch.as_tensor(a, device="cuda")); en.step(a)
+    order = [(9 - L + r) % L for r in range(L)]  # physical rows, oldest first
+    probe = [0, 1, n_envs // 2, n_envs - 1]
+    for name in _abi.LOG_DTYPES:
+        t = et._log_rows(name, None, order)
+        h = en._log_rows(name, None, order)
+        assert tuple(t.shape) == h.shape == (L, n_envs)
+        np.testing.assert_array_equal(t.cpu().numpy(), h, err_msg=name)
+        newest = en._log_rows(name, order[-1], None)
+        np.testing.assert_array_equal(newest, h[-1], err_msg=name)
+    for e in probe:
+        hist = en.history(e)  # the env's current episode: the last len(hist) logged rows
+        idx = en._log_rows("idx", None, order)[:, e]
+        step = en._log_rows("step", None, order)[:, e]
+        n = len(hist)
+        np.testing.assert_array_equal(np.asarray(hist["idx"]), idx[L - n:])
+        np.testing.assert_array_equal(np.asarray(hist["step"]), step[L - n:])
+    et.close(); en.close()
