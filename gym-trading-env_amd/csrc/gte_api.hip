@@ -440,6 +440,22 @@ int gte_create(const gte_config* cfg, gte_env** out) {
           e = e < 1 ? 1 : (e > 64 / GTE_WAVES ? 64 / GTE_WAVES : e);
           while (e < 64 / GTE_WAVES && (int64_t)e * vpe < 64) ++e;
           epw = e;
+          // Round 3: where the lean copy loop applies (whole passes of 4 wave instructions per wave,
+          // gte_kernels.hip) it beats the small workgroups above — 262 144 envs: 4 per wave 149 us,
+          // 8: 139.8, 16: 137.8; 131 072: 4: 80, 8: 74, 16: 71-78; 100 003: 6: 62, 8: 58.7, 16: 60-67
+          // (profiles/r03_epw_hbm.log) — so take the smallest envs-per-wave the lean loop accepts, twice
+          // that from 200 000 envs on.
+          if (!(cfg->kernel_variant & 4096)) {
+            int lean_e = 0;
+            for (int c = 1; c <= 64 / GTE_WAVES; ++c)
+              if (((int64_t)c * vpe) % 256 == 0 && (int64_t)c * p.W <= 512) { lean_e = c; break; }
+            if (lean_e) {
+              int c = lean_e;
+              while (c * 2 <= 64 / GTE_WAVES && (int64_t)c * vpe < 1280 && (int64_t)c * 2 * p.W <= 512) c *= 2;
+              if ((int64_t)p.N >= 200000 && c * 2 <= 64 / GTE_WAVES && (int64_t)c * 2 * p.W <= 512) c *= 2;
+              epw = c;
+            }
+          }
         }
       }
     }
