@@ -867,3 +867,27 @@ def test_log_columns_as_strided_views_of_the_records(n_envs):
         np.testing.assert_array_equal(np.asarray(hist["idx"]), idx[L - n:])
         np.testing.assert_array_equal(np.asarray(hist["step"]), step[L - n:])
     et.close(); en.close()
+
+
+def test_batched_history_reward_assignment_writes_the_newest_log_row():
+    """`history["reward", -1] = value` (environments.py:267) on the batch: `gte_set_log_reward`
+    writes the reward field of the newest row of every env's record (a strided device copy)."""
+    import torch
+    import gym_trading_env_amd as gte
+    feat, close = _walk(5, 600, 4, sigma=1e-2)
+    env = gte.BatchedTradingEnv(make_df(feat, close), 300, positions=[-1, 0, 1], windows=3, seed=2,
+                                output="torch", log_steps=4, max_episode_duration=50)
+    env.reset()
+    for k in range(6):
+        env.step(torch.randint(0, 3, (300,), dtype=torch.int32, device="cuda"))
+    h = env.batched_history()
+    before = {c: np.asarray(h[c, -1]).copy() for c in ("portfolio_valuation", "idx")}  # (np.asarray copies a DeviceArray to the host)
+    older = np.asarray(h["reward", -2]).copy()
+    value = torch.arange(300, dtype=torch.float64, device="cuda") * 0.5 - 7.0
+    h["reward", -1] = value
+    h2 = env.batched_history()
+    np.testing.assert_array_equal(np.asarray(h2["reward", -1]), value.cpu().numpy())
+    np.testing.assert_array_equal(np.asarray(h2["reward", -2]), older)  # the neighbours are untouched
+    for c, v in before.items():
+        np.testing.assert_array_equal(np.asarray(h2[c, -1]), v, err_msg=c)
+    env.close()
