@@ -641,8 +641,9 @@ def test_apply_reward_and_dynamic_columns_entry_points():
         a.close(); b.close()
 
 
-@pytest.mark.parametrize("mode", ["next_step", "same_step", "disabled"])
-def test_trajectory_row_written_by_the_step_kernel_equals_the_separate_launch(mode):
+@pytest.mark.parametrize("mode,N", [("next_step", 193), ("same_step", 193), ("disabled", 193),
+                                    ("next_step", 20_000), ("same_step", 20_000)])
+def test_trajectory_row_written_by_the_step_kernel_equals_the_separate_launch(mode, N):
     """With `log_steps` the step kernel's phase A writes the trajectory row itself; kernel_variant
     bit 1024 keeps round 1's separate log launch.  Every column of every row must be identical,
     resets and frozen envs included."""
@@ -650,7 +651,7 @@ def test_trajectory_row_written_by_the_step_kernel_equals_the_separate_launch(mo
     from gym_trading_env_amd import _abi
     from gym_trading_env_amd.batched import BatchedTradingEnv
     rng = np.random.default_rng(11)
-    T, N, L = 300, 193, 5
+    T, L = 300, 5  # (20 000 envs: several workgroups per CU and the L2-affinity order, rows through LDS)
     feat = rng.normal(size=(T, 6)).astype(np.float32)
     close = 100 * np.exp(np.cumsum(rng.normal(0, 3e-2, T)))
     kw = dict(num_envs=N, seed=4, positions=[-1, 0, 0.5, 2], windows=3, trading_fees=1e-3,
@@ -660,7 +661,7 @@ def test_trajectory_row_written_by_the_step_kernel_equals_the_separate_launch(mo
     b = BatchedTradingEnv((feat, close), kernel_variant=1024, **kw)   # separate launch
     a.reset(); b.reset()
     g = torch.Generator(device="cuda").manual_seed(2)
-    for k in range(40):
+    for k in range(40 if N < 1000 else 14):
         act = torch.randint(-1, 4, (N,), dtype=torch.int32, device="cuda", generator=g)
         ra = a.step(act); rb = b.step(act)
         for x, y in zip(ra[:4], rb[:4]):
