@@ -654,7 +654,7 @@ def test_trajectory_row_written_by_the_step_kernel_equals_the_separate_launch(mo
     T, L = 300, 5  # (20 000 envs: several workgroups per CU and the L2-affinity order, rows through LDS)
     feat = rng.normal(size=(T, 6)).astype(np.float32)
     close = 100 * np.exp(np.cumsum(rng.normal(0, 3e-2, T)))
-    kw = dict(num_envs=N, seed=4, positions=[-1, 0, 0.5, 2], windows=3, trading_fees=1e-3,
+    kw = dict(num_envs=N, seed=4, positions=[-1, 0, 0.5, 2], windows=3 if N < 1000 else 16, trading_fees=1e-3,
               borrow_interest_rate=1e-3, max_episode_duration=9, output="torch", log_steps=L,
               autoreset=mode, final_obs=(mode == "same_step"))
     a = BatchedTradingEnv((feat, close), kernel_variant=2048, **kw)   # row written in the kernel
